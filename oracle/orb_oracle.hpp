@@ -1,0 +1,120 @@
+// CPU ORACLE — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// Scalar restatement of the reference's ORB front end (ORBextractor, the
+// Frame grid query and the ORBmatcher Hamming routines) used only as the
+// checker in tests/, in __graft_entry__.smoke() and as bench.py's timed CPU
+// baseline.  Nothing in the product library links or loads it.
+//
+// PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures
+// for this path, its three hot-path sources do not compile as written, and
+// their pixel arithmetic lives in OpenCV 4.2, which is neither vendored nor
+// installed.  The OpenCV primitives (resize, GaussianBlur, FAST, fastAtan2,
+// cvRound) are therefore restated here from their published algorithms and
+// anchored on the reference's call sites (cited per function).  The only
+// vendored cross-check is DBoW2's FORB::distance for the Hamming distance.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace orbo {
+
+// Behaviour switches.  Each bit selects the text of the fork where it differs
+// (compile-clean, deterministic) from upstream ORB-SLAM2.
+enum : unsigned {
+    Q_RESIZE_AREA     = 1u << 0,  // src/ORBextractor.cc:931 INTER_AREA (upstream INTER_LINEAR)
+    Q_UMAX_FORK       = 1u << 1,  // src/ORBextractor.cc:431 compares umax[v] (upstream umax[v0])
+    Q_DIVIDE_N3       = 1u << 2,  // src/ORBextractor.cc:567-568 stray ';' : n3 always bNoMore, n4 never
+    Q_GRID_EXCLUSIVE  = 1u << 3,  // src/Frame.cc:101,110,112 '<' loop bounds and '>' row test
+    Q_WINDOW_CIRCULAR = 1u << 4,  // src/Frame.cc:133 dx^2+dy^2 < r^2 (upstream |dx|<r && |dy|<r)
+    Q_GAUSS_LEGACY    = 1u << 5,  // OpenCV <= 4.1 8-bit Gaussian taps {18,34,49,55,49,34,18}
+    Q_LIBM_TRIG       = 1u << 6,  // oracle only: cosf/sinf from libm instead of the portable routine
+    QUIRKS_FORK       = Q_RESIZE_AREA | Q_UMAX_FORK | Q_DIVIDE_N3 | Q_GRID_EXCLUSIVE | Q_WINDOW_CIRCULAR,
+    QUIRKS_CANONICAL  = 0u,
+};
+
+// Same layout as cv::KeyPoint (28 bytes).
+struct KeyPoint {
+    float x, y, size, angle, response;
+    int octave, class_id;
+};
+
+struct Image {
+    int w = 0, h = 0;
+    std::vector<uint8_t> px;  // row-major, stride == w
+    uint8_t* row(int y) { return px.data() + (size_t)y * w; }
+    const uint8_t* row(int y) const { return px.data() + (size_t)y * w; }
+};
+
+// ---- rounding helpers (OpenCV semantics) ----------------------------------
+int cvRound(float v);
+int cvRound(double v);
+int cvFloor(double v);
+int cvCeil(double v);
+
+// ---- OpenCV 4.2 primitives restated ----------------------------------------
+void resizeArea(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride);
+void resizeLinear(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride);
+void gaussianBlur7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride, bool legacy);
+void fastDetect(const uint8_t* img, int stride, int w, int h, int threshold, bool nms, std::vector<KeyPoint>& out);
+int fastCornerScore(const uint8_t* p, int stride, int threshold);
+float fastAtan2(float y, float x);
+void sincosPortable(float x, float* s, float* c);
+
+// ---- ORBextractor -----------------------------------------------------------
+class Extractor {
+public:
+    Extractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, unsigned quirks);
+
+    // operator(): src/ORBextractor.cc:448-509 with the truncated tail restored.
+    void extract(const uint8_t* img, int w, int h, int stride, std::vector<KeyPoint>& kps, std::vector<uint8_t>& desc);
+
+    void computePyramid(const uint8_t* img, int w, int h, int stride);
+    void computeKeyPointsOctTree(std::vector<std::vector<KeyPoint>>& all);
+    std::vector<KeyPoint> distributeOctTree(const std::vector<KeyPoint>& keys, int minX, int maxX, int minY, int maxY, int N) const;
+
+    int nfeatures;
+    double scaleFactor;  // double member, as include/ORBextractor.h:88
+    int nlevels, iniThFAST, minThFAST;
+    unsigned quirks;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    std::vector<int> mnFeaturesPerLevel, umax;
+    std::vector<Image> pyramid;                 // level images (the ROI part of mvImagePyramid)
+    // per-stage dumps of the last extract() for stage-wise parity tests
+    std::vector<Image> blurred;                 // GaussianBlur output per level (empty if level had no keypoints)
+    std::vector<std::vector<KeyPoint>> fastKeys;   // vToDistributeKeys per level
+    std::vector<std::vector<KeyPoint>> levelKeys;  // per level after quadtree + orientation (level coordinates)
+};
+
+float icAngle(const Image& im, float px, float py, const std::vector<int>& umax);
+void orbDescriptor(const Image& blurred, float px, float py, float angleDeg, bool libmTrig, uint8_t* desc);
+
+// ---- Frame grid + ORBmatcher --------------------------------------------------
+int hammingBitHack(const uint8_t* a, const uint8_t* b);   // src/ORBmatcher.cc:460-476 literal
+int hammingPopcount(const uint8_t* a, const uint8_t* b);  // 4 x popcount64
+
+struct FrameGrid {  // the part of Frame the matcher reads
+    int N = 0;
+    float minX = 0, maxX = 0, minY = 0, maxY = 0, wInv = 0, hInv = 0;
+    const KeyPoint* keys = nullptr;
+    const uint8_t* desc = nullptr;
+    std::vector<std::vector<int>> cells;  // [ix*48+iy]
+    void build(const KeyPoint* k, const uint8_t* d, int n, int imgW, int imgH);
+    std::vector<int> featuresInArea(float x, float y, float r, int minLevel, int maxLevel, unsigned quirks) const;
+};
+
+void computeThreeMaxima(const int* counts, int L, int& i1, int& i2, int& i3);
+
+int searchForInitialization(const FrameGrid& F1, const FrameGrid& F2, float* prevXY, int* matches12,
+                            int windowSize, float nnratio, bool checkOri, unsigned quirks);
+
+// Kernel-level form of SearchByProjection(Frame&,const Frame&,...): the projection is the caller's.
+int searchByProjection(const float* u, const float* v, const float* radius, const int* minLevel, const int* maxLevel,
+                       const float* qangle, const uint8_t* qdesc, const uint8_t* qobs, int nq, const FrameGrid& F2,
+                       const uint8_t* occupied2, int* match2 /*n2, -1 or query idx*/, int thHigh, bool checkOri,
+                       unsigned quirks);
+
+void bruteForceTop2(const uint8_t* q, int nq, const uint8_t* db, int64_t nd, int32_t* bestIdx, uint16_t* bestDist,
+                    uint16_t* secondDist);
+
+}  // namespace orbo
