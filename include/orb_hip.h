@@ -1,0 +1,201 @@
+/* liborbhip — C ABI of the MI355X (gfx950) ORB front end.
+ *
+ * The reference (JiahangWu/ORB_SLAM2) has no FFI layer: its boundary for this
+ * path is the C++ class API called from Tracking.  The drop-in C++ classes in
+ * orb_slam2_amd/cpp/ (same names and signatures as include/ORBextractor.h,
+ * include/ORBmatcher.h, include/Frame.h of the reference) call the functions
+ * below; so do the ctypes binding orb_slam2_amd/binding.py and the tests.
+ *
+ * Conventions: every function returns 0 (ORB_OK) or a negative orb_status;
+ * orb_last_error() gives the message of the calling thread's last failure.
+ * No C++ types, exceptions or torch types cross this boundary.  A context is
+ * single-threaded (like one ORBextractor object, which owns its pyramid);
+ * distinct contexts may be used from distinct threads / on distinct devices.
+ * Pointers named d_* are device pointers on the context's device, all others
+ * are host pointers.  `stream` is a hipStream_t passed as void* (NULL = the
+ * null stream).  The *_device entry points enqueue work and return without
+ * synchronising.
+ */
+#ifndef ORB_HIP_H
+#define ORB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    ORB_OK = 0,
+    ORB_ERR_INVALID = -1,     /* bad argument */
+    ORB_ERR_UNSUPPORTED = -2, /* configuration the kernels do not cover (stated in the message) */
+    ORB_ERR_HIP = -3,         /* a HIP runtime call failed */
+    ORB_ERR_CAPACITY = -4,    /* an output or internal buffer was too small; nothing was truncated silently */
+    ORB_ERR_NOMEM = -5
+} orb_status;
+
+/* Behaviour switches: where the fork's text compiles but differs from upstream
+ * ORB-SLAM2, the fork's behaviour is selectable.  ORB_QUIRKS_FORK reproduces
+ * the reference as written, ORB_QUIRKS_CANONICAL upstream. */
+enum {
+    ORB_Q_RESIZE_AREA = 1u << 0,     /* src/ORBextractor.cc:931 INTER_AREA (upstream INTER_LINEAR) */
+    ORB_Q_UMAX_FORK = 1u << 1,       /* src/ORBextractor.cc:431 */
+    ORB_Q_DIVIDE_N3 = 1u << 2,       /* src/ORBextractor.cc:567-568 */
+    ORB_Q_GRID_EXCLUSIVE = 1u << 3,  /* src/Frame.cc:101,110,112 */
+    ORB_Q_WINDOW_CIRCULAR = 1u << 4, /* src/Frame.cc:133 */
+    ORB_Q_GAUSS_LEGACY = 1u << 5,    /* OpenCV <= 4.1 Gaussian taps {18,34,49,55,49,34,18} */
+    ORB_QUIRKS_FORK = 0x1f,
+    ORB_QUIRKS_CANONICAL = 0
+};
+
+typedef struct orb_ctx orb_ctx; /* extractor + windowed matcher state on one device */
+typedef struct orb_bf orb_bf;   /* one shard of a brute-force descriptor database */
+
+/* Constructor arguments of ORBextractor (include/ORBextractor.h:36) plus sizing. */
+typedef struct {
+    int nfeatures;
+    float scale_factor;
+    int nlevels;
+    int ini_th_fast;
+    int min_th_fast;
+    int max_width, max_height; /* largest frame the context will be given */
+    int max_batch;             /* largest number of frames (or frame pairs) per call */
+    int device;                /* HIP device ordinal */
+    unsigned quirks;
+} orb_params;
+
+/* Same layout as cv::KeyPoint (28 bytes). */
+typedef struct {
+    float x, y, size, angle, response;
+    int octave, class_id;
+} orb_keypoint;
+
+/* ---- ORBextractor ------------------------------------------------------- */
+
+/* ORBextractor::ORBextractor, src/ORBextractor.cc:369-436. */
+int orb_create(const orb_params* params, orb_ctx** out);
+void orb_destroy(orb_ctx* ctx);
+
+/* Upper bound of keypoints one frame can produce (sum over levels of quota+3,
+ * the quadtree never trims): size kps/desc buffers with it. */
+int orb_max_keypoints_per_frame(const orb_ctx* ctx);
+
+/* ORBextractor::operator()(image, mask, keypoints, descriptors),
+ * src/ORBextractor.cc:448-509 (mask ignored, as there).  8-bit single channel
+ * image in host memory; keypoints level-major in the reference's order,
+ * descriptors cap x 32 bytes.  An empty image (w or h == 0) yields *n_out = 0. */
+int orb_extract(orb_ctx* ctx, const uint8_t* img, int w, int h, int stride, orb_keypoint* kps, uint8_t* desc, int cap,
+                int* n_out);
+
+/* The same over n independent frames of one size (n <= max_batch).  Frame f
+ * writes kps[f*cap_per_frame ..] and desc[f*cap_per_frame*32 ..], n_out[f]. */
+int orb_extract_batch(orb_ctx* ctx, const uint8_t* const* imgs, int n, int w, int h, int stride, orb_keypoint* kps,
+                      uint8_t* desc, int cap_per_frame, int* n_out);
+
+/* The same with every buffer resident in device memory: frame f starts at
+ * d_imgs + f*frame_stride.  Asynchronous on `stream`. */
+int orb_extract_batch_device(orb_ctx* ctx, const uint8_t* d_imgs, int n, int w, int h, int stride,
+                             int64_t frame_stride, orb_keypoint* d_kps, uint8_t* d_desc, int cap_per_frame,
+                             int* d_n_out, void* stream);
+
+/* After a *_device call has completed: 0 if no internal capacity or depth
+ * limit was hit by the last batch, else ORB_ERR_CAPACITY (synchronises). */
+int orb_check_last_batch(orb_ctx* ctx);
+
+/* ORBextractor::mvImagePyramid[level] (include/ORBextractor.h:71) of frame
+ * `frame` of the last batch, copied to host memory (ROI pixels, no padding). */
+int orb_get_pyramid_level(orb_ctx* ctx, int frame, int level, uint8_t* dst, int dst_stride, int* w, int* h);
+
+/* GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares (include/ORBextractor.h:50-68), the per-level
+ * quotas mnFeaturesPerLevel and the 16-entry umax table.  NULL = skip. */
+int orb_get_tables(const orb_ctx* ctx, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int* per_level,
+                   int* umax);
+
+/* Stage access for parity tests: keys handed to DistributeOctTree for
+ * (frame, level) of the last batch, in the reference's order
+ * (src/ORBextractor.cc:862-867): x, y relative to the 16-pixel border and the
+ * FAST score.  Returns the count through *n_out (writes at most cap). */
+int orb_debug_get_fast_keys(orb_ctx* ctx, int frame, int level, int* xs, int* ys, int* scores, int cap, int* n_out);
+
+/* Stand-alone stages (host buffers), the kernels of the pipeline run alone:
+ * cv::resize as called at src/ORBextractor.cc:926-931 (area != 0: INTER_AREA),
+ * cv::GaussianBlur as called at :493. */
+int orb_resize(orb_ctx* ctx, const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride,
+               int area);
+int orb_gaussian_blur(orb_ctx* ctx, const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
+
+/* ---- ORBmatcher ---------------------------------------------------------- */
+
+/* ORBmatcher::DescriptorDistance, src/ORBmatcher.cc:460-476 (host, pure). */
+int orb_hamming(const uint8_t a[32], const uint8_t b[32]);
+
+/* ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:26-136, with the grid
+ * query Frame::GetFeaturesInArea (src/Frame.cc:86-144) inside.  Frames are
+ * given as keypoints + descriptors (mvKeysUn == mvKeys: no distortion) and the
+ * image size that defines the 64x48 grid.  prev_xy (2*n1 floats) is
+ * vbPrevMatched in/out, matches12 (n1 ints) is vnMatches12 out. */
+int orb_match_window(orb_ctx* ctx, const orb_keypoint* k1, const uint8_t* d1, int n1, const orb_keypoint* k2,
+                     const uint8_t* d2, int n2, int img_w, int img_h, float* prev_xy, int* matches12, int window,
+                     float nnratio, int check_ori, int* nmatches);
+
+/* The same over npairs frame pairs resident in device memory (npairs <=
+ * max_batch).  Pair p reads d_k1 + p*stride1 keypoints, d_d1 + p*stride1*32
+ * descriptor bytes, d_n1[p] valid entries (likewise frame 2), and
+ * reads/writes d_prev_xy + p*stride1*2, d_matches12 + p*stride1, d_nmatches[p]. */
+int orb_match_window_batch_device(orb_ctx* ctx, int npairs, const orb_keypoint* d_k1, const uint8_t* d_d1,
+                                  const int* d_n1, int stride1, const orb_keypoint* d_k2, const uint8_t* d_d2,
+                                  const int* d_n2, int stride2, int img_w, int img_h, float* d_prev_xy,
+                                  int* d_matches12, int window, float nnratio, int check_ori, int* d_nmatches,
+                                  void* stream);
+
+/* Kernel-level form of ORBmatcher::SearchByProjection(Frame&, const Frame&,
+ * th, bMono), src/ORBmatcher.cc:279-408: the caller projects the last frame's
+ * map points (lines :302-331 are pose algebra on host objects) and passes per
+ * query the pixel (u,v), the search radius, the octave range of the window
+ * query, the keypoint angle, the map point's descriptor and whether the map
+ * point has observations; occupied2[i2] != 0 marks current-frame keypoints
+ * that already hold an observed map point.  match2[i2] = index of the query
+ * whose map point keypoint i2 holds afterwards, or -1. */
+int orb_match_projected(orb_ctx* ctx, const float* u, const float* v, const float* radius, const int* min_level,
+                        const int* max_level, const float* qangle, const uint8_t* qdesc, const uint8_t* qobs, int nq,
+                        const orb_keypoint* k2, const uint8_t* d2, int n2, int img_w, int img_h,
+                        const uint8_t* occupied2, int* match2, int th_high, int check_ori, int* nmatches);
+
+/* ---- brute-force top-2 (relocalisation / loop-candidate scale) ----------- */
+
+/* Dense scan with the best / second-best rule of src/ORBmatcher.cc:53-76:
+ * best = smallest distance, lowest database index among equals; second =
+ * second-smallest distance counted with multiplicity. */
+int orb_bf_create(int device, orb_bf** out);
+void orb_bf_destroy(orb_bf* bf);
+
+/* Load this shard's rows (n x 32 bytes, host memory); global_base = index of
+ * its first row in the whole database. */
+int orb_bf_set_database(orb_bf* bf, const uint8_t* db, int64_t n, int64_t global_base);
+/* The same from device memory; the shard keeps the pointer (no copy). */
+int orb_bf_set_database_device(orb_bf* bf, const uint8_t* d_db, int64_t n, int64_t global_base);
+
+/* Whole query on one shard, host buffers. */
+int orb_bf_query_top2(orb_bf* bf, const uint8_t* q, int nq, int32_t* best_idx, uint16_t* best_dist,
+                      uint16_t* second_dist);
+
+/* Per-shard result in packed form, device buffers, asynchronous:
+ * d_packed[i] = best_dist << 48 | second_dist << 32 | global index of best
+ * (0xFFFF / 0xFFFFFFFF when the shard holds fewer than 1 / 2 rows). */
+int orb_bf_query_packed_device(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t* d_packed, void* stream);
+
+/* Merge nshards packed results per query (d_gathered[s*nq + i], the layout an
+ * all-gather produces) into the final answer; equals a scan of the whole
+ * database.  Device buffers, asynchronous. */
+int orb_bf_merge_packed_device(int device, const uint64_t* d_gathered, int nshards, int nq, int32_t* d_best_idx,
+                               uint16_t* d_best_dist, uint16_t* d_second_dist, void* stream);
+
+/* ---- misc ------------------------------------------------------------------ */
+const char* orb_last_error(void);
+const char* orb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORB_HIP_H */

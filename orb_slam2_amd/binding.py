@@ -1,0 +1,262 @@
+"""ctypes binding of liborbhip.so (include/orb_hip.h).
+
+Host-array entry points take numpy arrays; the *_device entry points take
+torch CUDA tensors (torch is only the owner of device memory and streams).
+There is no CPU fallback: if the library cannot be loaded, importing the
+compute classes fails with the loader's error.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liborbhip.so")
+
+ORB_Q_RESIZE_AREA, ORB_Q_UMAX_FORK, ORB_Q_DIVIDE_N3, ORB_Q_GRID_EXCLUSIVE, ORB_Q_WINDOW_CIRCULAR, ORB_Q_GAUSS_LEGACY = (
+    1 << i for i in range(6)
+)
+ORB_QUIRKS_FORK = 0x1F
+ORB_QUIRKS_CANONICAL = 0
+
+KP_DTYPE = np.dtype(
+    [("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")]
+)
+
+EXPORTS = [
+    "orb_create", "orb_destroy", "orb_max_keypoints_per_frame", "orb_extract", "orb_extract_batch",
+    "orb_extract_batch_device", "orb_check_last_batch", "orb_get_pyramid_level", "orb_get_tables",
+    "orb_debug_get_fast_keys", "orb_resize", "orb_gaussian_blur", "orb_hamming", "orb_match_window",
+    "orb_match_window_batch_device", "orb_match_projected", "orb_bf_create", "orb_bf_destroy", "orb_bf_set_database",
+    "orb_bf_set_database_device", "orb_bf_query_top2", "orb_bf_query_packed_device", "orb_bf_merge_packed_device",
+    "orb_last_error", "orb_version",
+]
+
+
+class OrbParams(C.Structure):
+    _fields_ = [
+        ("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int), ("ini_th_fast", C.c_int),
+        ("min_th_fast", C.c_int), ("max_width", C.c_int), ("max_height", C.c_int), ("max_batch", C.c_int),
+        ("device", C.c_int), ("quirks", C.c_uint),
+    ]
+
+
+class OrbError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("liborbhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: build it with `make -C orb_slam2_amd/csrc` (hipcc, gfx950)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.orb_last_error.restype = C.c_char_p
+        L.orb_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise OrbError(rc, lib().orb_last_error().decode())
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _dp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(stream):
+    if stream is None:
+        import torch
+
+        stream = torch.cuda.current_stream()
+    return C.c_void_p(stream.cuda_stream)
+
+
+def hamming(a, b):
+    """ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:460-476)."""
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return lib().orb_hamming(_p(a), _p(b))
+
+
+class Context:
+    """One ORBextractor (+ windowed matcher state) on one device."""
+
+    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, max_width=640, max_height=480,
+                 max_batch=1, device=0, quirks=ORB_QUIRKS_FORK):
+        self.params = OrbParams(nfeatures, scale, nlevels, ini_th, min_th, max_width, max_height, max_batch, device, quirks)
+        self.h = C.c_void_p()
+        self.nlevels = nlevels
+        _check(lib().orb_create(C.byref(self.params), C.byref(self.h)))
+        self.cap = lib().orb_max_keypoints_per_frame(self.h)
+
+    def close(self):
+        if getattr(self, "h", None) and self.h:
+            lib().orb_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    # ---- extraction, host arrays -----------------------------------------------------
+    def extract(self, img):
+        """ORBextractor::operator()(image, mask, keypoints, descriptors)."""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape if img.ndim == 2 else (0, 0)
+        kps = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n = C.c_int(0)
+        _check(lib().orb_extract(self.h, _p(img), w, h, img.strides[0] if img.ndim == 2 and h else w, _p(kps), _p(desc), self.cap, C.byref(n)))
+        return kps[: n.value].copy(), desc[: n.value].copy()
+
+    def extract_batch(self, imgs):
+        imgs = [np.ascontiguousarray(i, np.uint8) for i in imgs]
+        n = len(imgs)
+        h, w = imgs[0].shape
+        assert all(i.shape == (h, w) for i in imgs)
+        ptrs = (C.c_void_p * n)(*[i.ctypes.data for i in imgs])
+        kps = np.zeros((n, self.cap), KP_DTYPE)
+        desc = np.zeros((n, self.cap, 32), np.uint8)
+        cnt = np.zeros(n, np.int32)
+        _check(lib().orb_extract_batch(self.h, ptrs, n, w, h, imgs[0].strides[0], _p(kps), _p(desc), self.cap, _p(cnt)))
+        return [(kps[f, : cnt[f]].copy(), desc[f, : cnt[f]].copy()) for f in range(n)]
+
+    # ---- extraction, device tensors ----------------------------------------------------
+    def extract_batch_device(self, d_imgs, d_kps, d_desc, d_counts, stream=None):
+        """d_imgs: uint8 CUDA tensor [n, h, w] (any row / frame stride); outputs are
+        CUDA tensors: d_kps uint8 [n, cap, 28], d_desc uint8 [n, cap, 32], d_counts int32 [n]."""
+        n, h, w = d_imgs.shape
+        assert d_imgs.stride(2) == 1
+        cap = d_kps.shape[1]
+        _check(lib().orb_extract_batch_device(
+            self.h, _dp(d_imgs), n, w, h, d_imgs.stride(1), C.c_int64(d_imgs.stride(0)), _dp(d_kps), _dp(d_desc), cap,
+            _dp(d_counts), _stream(stream)))
+
+    def check_last_batch(self):
+        _check(lib().orb_check_last_batch(self.h))
+
+    # ---- stage access ---------------------------------------------------------------------
+    def tables(self):
+        L = self.nlevels
+        f = [np.zeros(L, np.float32) for _ in range(4)]
+        per = np.zeros(L, np.int32)
+        um = np.zeros(16, np.int32)
+        _check(lib().orb_get_tables(self.h, _p(f[0]), _p(f[1]), _p(f[2]), _p(f[3]), _p(per), _p(um)))
+        return dict(scale=f[0], inv_scale=f[1], sigma2=f[2], inv_sigma2=f[3], per_level=per, umax=um)
+
+    def pyramid_level(self, frame, level):
+        """mvImagePyramid[level] of a frame of the last batch."""
+        w, h = C.c_int(), C.c_int()
+        _check(lib().orb_get_pyramid_level(self.h, frame, level, None, 0, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        _check(lib().orb_get_pyramid_level(self.h, frame, level, _p(out), w.value, C.byref(w), C.byref(h)))
+        return out
+
+    def fast_keys(self, frame, level):
+        n = C.c_int(0)
+        _check(lib().orb_debug_get_fast_keys(self.h, frame, level, None, None, None, 0, C.byref(n)))
+        xs, ys, sc = (np.zeros(max(n.value, 1), np.int32) for _ in range(3))
+        _check(lib().orb_debug_get_fast_keys(self.h, frame, level, _p(xs), _p(ys), _p(sc), n.value, C.byref(n)))
+        return xs[: n.value], ys[: n.value], sc[: n.value]
+
+    def resize(self, src, dw, dh, area=True):
+        src = np.ascontiguousarray(src, np.uint8)
+        dst = np.zeros((dh, dw), np.uint8)
+        _check(lib().orb_resize(self.h, _p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw, int(area)))
+        return dst
+
+    def gaussian_blur(self, src):
+        src = np.ascontiguousarray(src, np.uint8)
+        dst = np.zeros_like(src)
+        _check(lib().orb_gaussian_blur(self.h, _p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dst.strides[0]))
+        return dst
+
+    # ---- matching ---------------------------------------------------------------------------
+    def match_window(self, k1, d1, k2, d2, img_w, img_h, prev_xy, window=100, nnratio=0.9, check_ori=True):
+        """ORBmatcher::SearchForInitialization.  Returns (nmatches, matches12, prev_xy_out)."""
+        k1 = np.ascontiguousarray(k1, KP_DTYPE)
+        k2 = np.ascontiguousarray(k2, KP_DTYPE)
+        d1 = np.ascontiguousarray(d1, np.uint8)
+        d2 = np.ascontiguousarray(d2, np.uint8)
+        prev = np.ascontiguousarray(prev_xy, np.float32).copy()
+        m12 = np.zeros(max(len(k1), 1), np.int32)
+        nm = C.c_int(0)
+        _check(lib().orb_match_window(self.h, _p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), img_w, img_h, _p(prev),
+                                      _p(m12), window, C.c_float(nnratio), int(check_ori), C.byref(nm)))
+        return nm.value, m12[: len(k1)], prev
+
+    def match_window_batch_device(self, d_k1, d_d1, d_n1, d_k2, d_d2, d_n2, img_w, img_h, d_prev, d_m12, d_nm,
+                                  window=100, nnratio=0.9, check_ori=True, stream=None):
+        npairs, s1 = d_k1.shape[0], d_k1.shape[1]
+        s2 = d_k2.shape[1]
+        _check(lib().orb_match_window_batch_device(
+            self.h, npairs, _dp(d_k1), _dp(d_d1), _dp(d_n1), s1, _dp(d_k2), _dp(d_d2), _dp(d_n2), s2, img_w, img_h,
+            _dp(d_prev), _dp(d_m12), window, C.c_float(nnratio), int(check_ori), _dp(d_nm), _stream(stream)))
+
+    def match_projected(self, u, v, radius, min_level, max_level, qangle, qdesc, qobs, k2, d2, img_w, img_h,
+                        occupied2=None, th_high=100, check_ori=True):
+        """Search loop of ORBmatcher::SearchByProjection(Frame&, const Frame&, th, bMono)."""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        i32 = lambda a: np.ascontiguousarray(a, np.int32)
+        u8 = lambda a: None if a is None else np.ascontiguousarray(a, np.uint8)
+        u, v, radius, qangle = f32(u), f32(v), f32(radius), f32(qangle)
+        min_level, max_level = i32(min_level), i32(max_level)
+        qdesc, d2, qobs, occ = u8(qdesc), u8(d2), u8(qobs), u8(occupied2)
+        k2 = np.ascontiguousarray(k2, KP_DTYPE)
+        match2 = np.zeros(max(len(k2), 1), np.int32)
+        nm = C.c_int(0)
+        _check(lib().orb_match_projected(self.h, _p(u), _p(v), _p(radius), _p(min_level), _p(max_level), _p(qangle),
+                                         _p(qdesc), _p(qobs), len(u), _p(k2), _p(d2), len(k2), img_w, img_h, _p(occ),
+                                         _p(match2), th_high, int(check_ori), C.byref(nm)))
+        return nm.value, match2[: len(k2)]
+
+
+class BruteForce:
+    """One shard of a brute-force descriptor database on one device."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        self.device = device
+        _check(lib().orb_bf_create(device, C.byref(self.h)))
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None) and self.h:
+            lib().orb_bf_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def set_database(self, db, global_base=0):
+        db = np.ascontiguousarray(db, np.uint8)
+        _check(lib().orb_bf_set_database(self.h, _p(db), C.c_int64(len(db)), C.c_int64(global_base)))
+
+    def set_database_device(self, d_db, global_base=0):
+        self._keep = d_db  # the shard keeps the pointer, not a copy
+        _check(lib().orb_bf_set_database_device(self.h, _dp(d_db), C.c_int64(d_db.shape[0]), C.c_int64(global_base)))
+
+    def query_top2(self, q):
+        q = np.ascontiguousarray(q, np.uint8)
+        nq = len(q)
+        idx = np.zeros(nq, np.int32)
+        d1 = np.zeros(nq, np.uint16)
+        d2 = np.zeros(nq, np.uint16)
+        _check(lib().orb_bf_query_top2(self.h, _p(q), nq, _p(idx), _p(d1), _p(d2)))
+        return idx, d1, d2
+
+    def query_packed_device(self, d_q, d_packed, stream=None):
+        _check(lib().orb_bf_query_packed_device(self.h, _dp(d_q), d_q.shape[0], _dp(d_packed), _stream(stream)))
+
+
+def merge_packed_device(device, d_gathered, nshards, nq, d_idx, d_best, d_second, stream=None):
+    _check(lib().orb_bf_merge_packed_device(device, _dp(d_gathered), nshards, nq, _dp(d_idx), _dp(d_best), _dp(d_second), _stream(stream)))

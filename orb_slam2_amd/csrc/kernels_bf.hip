@@ -1,0 +1,376 @@
+// Brute-force Hamming top-2 over a descriptor database shard for gfx950.
+//
+// The unit of work is ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:460-476):
+// popcount of a 256-bit XOR, i.e. 8 x (v_xor_b32 + accumulating v_bcnt_u32_b32).
+// The scan applies the best / second-best rule of src/ORBmatcher.cc:53-76 to
+// every database row in index order.
+//
+// Mapping: one lane holds QPL query descriptors in registers (8 VGPRs each);
+// database rows are wave-uniform, so they arrive through scalar loads into
+// SGPRs and every comparison is VGPR x SGPR.  Rows are taken GROUP at a time;
+// the top-2 state (best distance, best row, second distance per query) is only
+// touched when some lane of the wave saw a distance below its current second
+// best, which for all but the first few thousand rows of a chunk is rare.
+// The database is cut into chunks along blockIdx.y so that a shard fills the
+// chip; per-chunk results are packed as best << 48 | second << 32 | global row
+// and combined by the same merge kernel that combines the shards of several GPUs.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "orb_internal.h"
+
+#define BF_QPL 4      // queries per lane
+#define BF_GROUP 4    // rows per inner step
+#define BF_NONE 0xFFFFu
+
+struct orb_bf {
+    int device = 0;
+    const uint8_t* d_db = nullptr;
+    bool ownsDb = false;
+    int64_t n = 0, globalBase = 0;
+    void* d_partial = nullptr;
+    size_t partialBytes = 0;
+    void* d_q = nullptr;
+    size_t qBytes = 0;
+    void* d_packed = nullptr;
+    size_t packedBytes = 0;
+    void* d_out = nullptr;
+    size_t outBytes = 0;
+    hipStream_t stream = nullptr;
+};
+
+#define HIP_TRY(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            orb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);   \
+            return ORB_ERR_HIP;                                                                         \
+        }                                                                                               \
+    } while (0)
+
+// popcount(x) + acc in one instruction; written as asm because the compiler
+// otherwise splits the chain into bcnt(x, 0) plus separate three-operand adds.
+static __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
+struct Row256 {  // one database row, wave-uniform (lives in SGPRs)
+    uint4 lo, hi;
+};
+
+static __device__ __forceinline__ Row256 load_row(const uint32_t* __restrict__ p) {
+    Row256 r;
+    r.lo = ((const uint4*)p)[0];
+    r.hi = ((const uint4*)p)[1];
+    return r;
+}
+
+static __device__ __forceinline__ uint32_t hamming256(const uint32_t (&a)[8], const Row256& r) {
+    uint32_t d = __builtin_popcount(a[0] ^ r.lo.x);
+    d = bcnt_acc(a[1] ^ r.lo.y, d);
+    d = bcnt_acc(a[2] ^ r.lo.z, d);
+    d = bcnt_acc(a[3] ^ r.lo.w, d);
+    d = bcnt_acc(a[4] ^ r.hi.x, d);
+    d = bcnt_acc(a[5] ^ r.hi.y, d);
+    d = bcnt_acc(a[6] ^ r.hi.z, d);
+    d = bcnt_acc(a[7] ^ r.hi.w, d);
+    return d;
+}
+
+static __device__ __forceinline__ void top2_update(uint32_t d, uint32_t row, uint32_t& bd, uint32_t& bi, uint32_t& sd) {
+    // strict '<' in scan order: an equal distance never replaces the best, but becomes the second best
+    if (d < sd) {
+        if (d < bd) {
+            sd = bd;
+            bd = d;
+            bi = row;
+        } else {
+            sd = d;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bf_top2(const uint32_t* __restrict__ q, int nq,
+                                                 const uint32_t* __restrict__ db, long long nd,
+                                                 long long rowsPerChunk, long long globalBase,
+                                                 unsigned long long* __restrict__ partial) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long qb = ((long long)blockIdx.x * 4 + wave) * (64 * BF_QPL);
+    if (qb >= nq) return;
+    uint32_t qv[BF_QPL][8];
+    uint32_t bd[BF_QPL], sd[BF_QPL], bi[BF_QPL];
+#pragma unroll
+    for (int j = 0; j < BF_QPL; j++) {
+        long long qi = qb + j * 64 + lane;
+        if (qi >= nq) qi = nq - 1;  // tail lanes compute on a valid row and are not written back
+        const uint4* p = (const uint4*)(q + qi * 8);
+        const uint4 lo = p[0], hi = p[1];
+        qv[j][0] = lo.x; qv[j][1] = lo.y; qv[j][2] = lo.z; qv[j][3] = lo.w;
+        qv[j][4] = hi.x; qv[j][5] = hi.y; qv[j][6] = hi.z; qv[j][7] = hi.w;
+        bd[j] = BF_NONE;
+        sd[j] = BF_NONE;
+        bi[j] = 0xFFFFFFFFu;
+    }
+    const long long r0 = (long long)blockIdx.y * rowsPerChunk;
+    const long long r1 = (r0 + rowsPerChunk < nd) ? r0 + rowsPerChunk : nd;
+    long long r = r0;
+    for (; r + BF_GROUP <= r1; r += BF_GROUP) {
+        const uint32_t* __restrict__ rows = db + r * 8;  // wave-uniform address: scalar loads
+        uint32_t d[BF_GROUP][BF_QPL];
+        Row256 rw[BF_GROUP];
+#pragma unroll
+        for (int g = 0; g < BF_GROUP; g++) rw[g] = load_row(rows + g * 8);
+        bool any = false;
+#pragma unroll
+        for (int g = 0; g < BF_GROUP; g++) {
+#pragma unroll
+            for (int j = 0; j < BF_QPL; j++) {
+                d[g][j] = hamming256(qv[j], rw[g]);
+                any |= d[g][j] < sd[j];
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(any)) {
+#pragma unroll
+            for (int g = 0; g < BF_GROUP; g++) {
+#pragma unroll
+                for (int j = 0; j < BF_QPL; j++) top2_update(d[g][j], (uint32_t)(r + g - r0), bd[j], bi[j], sd[j]);
+            }
+        }
+    }
+    for (; r < r1; r++) {
+        const Row256 row = load_row(db + r * 8);
+#pragma unroll
+        for (int j = 0; j < BF_QPL; j++) top2_update(hamming256(qv[j], row), (uint32_t)(r - r0), bd[j], bi[j], sd[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < BF_QPL; j++) {
+        const long long qi = qb + j * 64 + lane;
+        if (qi < nq) {
+            const unsigned long long idx =
+                (bd[j] == BF_NONE) ? 0xFFFFFFFFull : (unsigned long long)(globalBase + r0 + bi[j]) & 0xFFFFFFFFull;
+            partial[(long long)blockIdx.y * nq + qi] =
+                ((unsigned long long)bd[j] << 48) | ((unsigned long long)sd[j] << 32) | idx;
+        }
+    }
+}
+
+// Combine nshards packed candidates per query.  Inserting every shard's best
+// (distance, row) and second distance into one running top-2 equals scanning
+// the concatenated rows: the best is the smallest (distance, row), the second
+// the second-smallest distance with multiplicity.
+__global__ __launch_bounds__(256) void k_bf_merge(const unsigned long long* __restrict__ gathered, int nshards, int nq,
+                                                  unsigned long long* __restrict__ packedOut,
+                                                  int32_t* __restrict__ bestIdx, uint16_t* __restrict__ bestDist,
+                                                  uint16_t* __restrict__ secondDist) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq) return;
+    uint32_t bd = BF_NONE, sd = BF_NONE, bi = 0xFFFFFFFFu;
+    for (int s = 0; s < nshards; s++) {
+        const unsigned long long p = gathered[(long long)s * nq + i];
+        const uint32_t d = (uint32_t)(p >> 48), d2 = (uint32_t)(p >> 32) & 0xFFFFu, idx = (uint32_t)p;
+        if (d == BF_NONE) continue;
+        if (d < bd || (d == bd && idx < bi)) {
+            sd = bd;  // bd <= sd always, so the displaced best is the new second unless d2 beats it below
+            bd = d;
+            bi = idx;
+        } else if (d < sd) {
+            sd = d;
+        }
+        if (d2 < sd) sd = d2;
+    }
+    if (packedOut) packedOut[i] = ((unsigned long long)bd << 48) | ((unsigned long long)sd << 32) | bi;
+    if (bestIdx) bestIdx[i] = (bd == BF_NONE) ? -1 : (int32_t)bi;
+    if (bestDist) bestDist[i] = (uint16_t)bd;
+    if (secondDist) secondDist[i] = (uint16_t)sd;
+}
+
+extern "C" int orb_bf_create(int device, orb_bf** out) {
+    if (!out) {
+        orb_set_error("orb_bf_create: null argument");
+        return ORB_ERR_INVALID;
+    }
+    *out = nullptr;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) {
+        orb_set_error("device %d not present (%d devices)", device, ndev);
+        return ORB_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(device));
+    orb_bf* bf = new orb_bf();
+    bf->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&bf->stream, hipStreamNonBlocking));
+    *out = bf;
+    return ORB_OK;
+}
+
+static void bf_free(void*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+extern "C" void orb_bf_destroy(orb_bf* bf) {
+    if (!bf) return;
+    (void)hipSetDevice(bf->device);
+    (void)hipDeviceSynchronize();
+    if (bf->ownsDb) {
+        void* p = (void*)bf->d_db;
+        bf_free(p);
+    }
+    bf_free(bf->d_partial);
+    bf_free(bf->d_q);
+    bf_free(bf->d_packed);
+    bf_free(bf->d_out);
+    if (bf->stream) (void)hipStreamDestroy(bf->stream);
+    delete bf;
+}
+
+static int bf_ensure(void*& p, size_t& have, size_t need) {
+    if (need <= have) return ORB_OK;
+    bf_free(p);
+    have = 0;
+    hipError_t e = hipMalloc(&p, need);
+    if (e != hipSuccess) {
+        orb_set_error("hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+        return ORB_ERR_NOMEM;
+    }
+    have = need;
+    return ORB_OK;
+}
+
+extern "C" int orb_bf_set_database_device(orb_bf* bf, const uint8_t* d_db, int64_t n, int64_t global_base) {
+    if (!bf || n < 0 || (n > 0 && !d_db) || global_base < 0 || global_base + n > 0xFFFFFFFFll) {
+        orb_set_error("orb_bf_set_database: bad arguments (rows are indexed with 32 bits)");
+        return ORB_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(bf->device));
+    if (bf->ownsDb) {
+        HIP_TRY(hipDeviceSynchronize());
+        void* p = (void*)bf->d_db;
+        bf_free(p);
+        bf->ownsDb = false;
+    }
+    bf->d_db = d_db;
+    bf->n = n;
+    bf->globalBase = global_base;
+    return ORB_OK;
+}
+
+extern "C" int orb_bf_set_database(orb_bf* bf, const uint8_t* db, int64_t n, int64_t global_base) {
+    if (!bf || n < 0 || (n > 0 && !db)) {
+        orb_set_error("orb_bf_set_database: bad arguments");
+        return ORB_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(bf->device));
+    void* d = nullptr;
+    if (n > 0) {
+        hipError_t e = hipMalloc(&d, (size_t)n * 32);
+        if (e != hipSuccess) {
+            orb_set_error("hipMalloc(%zu) failed: %s", (size_t)n * 32, hipGetErrorString(e));
+            return ORB_ERR_NOMEM;
+        }
+        HIP_TRY(hipMemcpy(d, db, (size_t)n * 32, hipMemcpyHostToDevice));
+    }
+    int rc = orb_bf_set_database_device(bf, (const uint8_t*)d, n, global_base);
+    if (rc) {
+        if (d) (void)hipFree(d);
+        return rc;
+    }
+    bf->ownsDb = (d != nullptr);
+    return ORB_OK;
+}
+
+// Chunks along the database so that the launch has a few thousand wavefronts.
+static int bf_chunks(int nq, int64_t nd, long long* rowsPerChunk) {
+    const long long qWaves = (nq + 64 * BF_QPL - 1) / (64 * BF_QPL);
+    long long chunks = (8192 + qWaves - 1) / qWaves;
+    const long long maxChunks = std::max<long long>(1, nd / 4096);  // keep chunks long enough to amortise set-up
+    chunks = std::max<long long>(1, std::min<long long>(std::min<long long>(chunks, maxChunks), 1024));
+    long long rpc = (nd + chunks - 1) / chunks;
+    rpc = (rpc + BF_GROUP - 1) / BF_GROUP * BF_GROUP;
+    if (rpc < BF_GROUP) rpc = BF_GROUP;
+    chunks = std::max<long long>(1, (nd + rpc - 1) / rpc);
+    *rowsPerChunk = rpc;
+    return (int)chunks;
+}
+
+extern "C" int orb_bf_query_packed_device(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t* d_packed, void* stream) {
+    if (!bf || nq < 0 || (nq > 0 && (!d_q || !d_packed))) {
+        orb_set_error("orb_bf_query_packed_device: bad arguments");
+        return ORB_ERR_INVALID;
+    }
+    if (nq == 0) return ORB_OK;
+    HIP_TRY(hipSetDevice(bf->device));
+    hipStream_t st = (hipStream_t)stream;
+    long long rpc = BF_GROUP;
+    const int chunks = bf_chunks(nq, bf->n, &rpc);
+    int rc = bf_ensure(bf->d_partial, bf->partialBytes, (size_t)chunks * nq * 8);
+    if (rc) return rc;
+    const int qBlocks = (nq + 256 * BF_QPL - 1) / (256 * BF_QPL);
+    if (bf->n > 0) {
+        hipLaunchKernelGGL(k_bf_top2, dim3(qBlocks, chunks), dim3(256), 0, st, (const uint32_t*)d_q, nq,
+                           (const uint32_t*)bf->d_db, (long long)bf->n, rpc, (long long)bf->globalBase,
+                           (unsigned long long*)bf->d_partial);
+    } else {
+        HIP_TRY(hipMemsetAsync(bf->d_partial, 0xFF, (size_t)nq * 8, st));
+    }
+    hipLaunchKernelGGL(k_bf_merge, dim3((nq + 255) / 256), dim3(256), 0, st, (const unsigned long long*)bf->d_partial,
+                       chunks, nq, (unsigned long long*)d_packed, (int32_t*)nullptr, (uint16_t*)nullptr,
+                       (uint16_t*)nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        orb_set_error("brute-force launch failed: %s", hipGetErrorString(e));
+        return ORB_ERR_HIP;
+    }
+    return ORB_OK;
+}
+
+extern "C" int orb_bf_merge_packed_device(int device, const uint64_t* d_gathered, int nshards, int nq,
+                                          int32_t* d_best_idx, uint16_t* d_best_dist, uint16_t* d_second_dist,
+                                          void* stream) {
+    if (nshards < 1 || nq < 0 || (nq > 0 && !d_gathered)) {
+        orb_set_error("orb_bf_merge_packed_device: bad arguments");
+        return ORB_ERR_INVALID;
+    }
+    if (nq == 0) return ORB_OK;
+    HIP_TRY(hipSetDevice(device));
+    hipLaunchKernelGGL(k_bf_merge, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned long long*)d_gathered, nshards, nq, (unsigned long long*)nullptr, d_best_idx,
+                       d_best_dist, d_second_dist);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        orb_set_error("merge launch failed: %s", hipGetErrorString(e));
+        return ORB_ERR_HIP;
+    }
+    return ORB_OK;
+}
+
+extern "C" int orb_bf_query_top2(orb_bf* bf, const uint8_t* q, int nq, int32_t* best_idx, uint16_t* best_dist,
+                                 uint16_t* second_dist) {
+    if (!bf || nq < 0 || (nq > 0 && !q)) {
+        orb_set_error("orb_bf_query_top2: bad arguments");
+        return ORB_ERR_INVALID;
+    }
+    if (nq == 0) return ORB_OK;
+    HIP_TRY(hipSetDevice(bf->device));
+    int rc = bf_ensure(bf->d_q, bf->qBytes, (size_t)nq * 32);
+    if (!rc) rc = bf_ensure(bf->d_packed, bf->packedBytes, (size_t)nq * 8);
+    if (!rc) rc = bf_ensure(bf->d_out, bf->outBytes, (size_t)nq * 8);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(bf->d_q, q, (size_t)nq * 32, hipMemcpyHostToDevice, bf->stream));
+    rc = orb_bf_query_packed_device(bf, (const uint8_t*)bf->d_q, nq, (uint64_t*)bf->d_packed, bf->stream);
+    if (rc) return rc;
+    int32_t* dIdx = (int32_t*)bf->d_out;
+    uint16_t* dB = (uint16_t*)((uint8_t*)bf->d_out + (size_t)nq * 4);
+    uint16_t* dS = dB + nq;
+    rc = orb_bf_merge_packed_device(bf->device, (const uint64_t*)bf->d_packed, 1, nq, dIdx, dB, dS, bf->stream);
+    if (rc) return rc;
+    if (best_idx) HIP_TRY(hipMemcpyAsync(best_idx, dIdx, (size_t)nq * 4, hipMemcpyDeviceToHost, bf->stream));
+    if (best_dist) HIP_TRY(hipMemcpyAsync(best_dist, dB, (size_t)nq * 2, hipMemcpyDeviceToHost, bf->stream));
+    if (second_dist) HIP_TRY(hipMemcpyAsync(second_dist, dS, (size_t)nq * 2, hipMemcpyDeviceToHost, bf->stream));
+    HIP_TRY(hipStreamSynchronize(bf->stream));
+    return ORB_OK;
+}

@@ -1,0 +1,266 @@
+// Orientation, blur and rBRIEF descriptor per selected keypoint, and the final
+// keypoint record: IC_Angle (src/ORBextractor.cc:23-63), the 7x7 Gaussian blur
+// the reference applies to the whole level before describing it (:491-493),
+// computeOrbDescriptor (:67-103) and the tail of operator() (level scaling,
+// level-major output order).
+//
+// One wavefront per keypoint.  The 43x43 source window around the keypoint is
+// staged in LDS once; the 31x31 circular patch moments come from its centre,
+// and the blur is evaluated only on the 37x37 window the rotated sampling
+// pattern can reach (radius 18.4).  The blur is exact 8.8 fixed point, so this
+// equals blurring the whole level first.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#include "orb_internal.h"
+
+#define DESC_WAVES 4
+#define RAW_N 43
+#define RAW_P 44
+#define HB_P 38   // 37 columns of 16-bit horizontal sums
+#define BL_N 37
+#define BL_P 40
+
+__constant__ signed char c_pattern[256 * 4] = {
+#include "orb_pattern.inc"
+};
+
+static __device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+
+// cv::fastAtan2: every product / sum rounded on its own.
+static __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float s = (float)(180 / 3.14159265358979323846);
+    const float p1 = __fmul_rn(0.9997878412794807f, s);
+    const float p3 = __fmul_rn(-0.3258083974640975f, s);
+    const float p5 = __fmul_rn(0.1555786518463281f, s);
+    const float p7 = __fmul_rn(-0.04432655554792128f, s);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, (float)DBL_EPSILON));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, (float)DBL_EPSILON));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+// Sine / cosine for the pattern rotation: reduce by multiples of pi/2 in double
+// (two-constant Cody-Waite), fdlibm kernel polynomials in double, every
+// operation rounded on its own, one rounding to float.  |x| < 2^20.
+static __device__ __forceinline__ void sincos_portable(float xf, float* s, float* c) {
+    const double x = (double)xf;
+    const double invpio2 = 6.36619772367581382433e-01;
+    const double pio2_1 = 1.57079632673412561417e+00;
+    const double pio2_1t = 6.07710050650619224932e-11;
+    const double big = 6755399441055744.0;
+    double fn = __dadd_rn(__dmul_rn(x, invpio2), big);
+    fn = __dsub_rn(fn, big);
+    const int n = (int)fn;
+    double r = __dsub_rn(x, __dmul_rn(fn, pio2_1));
+    r = __dsub_rn(r, __dmul_rn(fn, pio2_1t));
+    const double z = __dmul_rn(r, r);
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double ps = S6;
+    ps = __dadd_rn(__dmul_rn(ps, z), S5);
+    ps = __dadd_rn(__dmul_rn(ps, z), S4);
+    ps = __dadd_rn(__dmul_rn(ps, z), S3);
+    ps = __dadd_rn(__dmul_rn(ps, z), S2);
+    ps = __dadd_rn(__dmul_rn(ps, z), S1);
+    const double sn = __dadd_rn(r, __dmul_rn(r, __dmul_rn(z, ps)));
+    double pc = C6;
+    pc = __dadd_rn(__dmul_rn(pc, z), C5);
+    pc = __dadd_rn(__dmul_rn(pc, z), C4);
+    pc = __dadd_rn(__dmul_rn(pc, z), C3);
+    pc = __dadd_rn(__dmul_rn(pc, z), C2);
+    pc = __dadd_rn(__dmul_rn(pc, z), C1);
+    const double cs = __dadd_rn(__dsub_rn(1.0, __dmul_rn(0.5, z)), __dmul_rn(z, __dmul_rn(z, pc)));
+    double so, co;
+    switch (n & 3) {
+        case 0: so = sn; co = cs; break;
+        case 1: so = cs; co = -sn; break;
+        case 2: so = -sn; co = -cs; break;
+        default: so = -cs; co = sn; break;
+    }
+    *s = (float)so;
+    *c = (float)co;
+}
+
+static __device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+static __device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __restrict__ g,
+                                                             const uint8_t* __restrict__ img0, int stride0,
+                                                             int64_t frameStride0, const uint8_t* __restrict__ pyr,
+                                                             int nframes, const uint32_t* __restrict__ selXY,
+                                                             const int* __restrict__ selScore,
+                                                             const int* __restrict__ levelCount,
+                                                             orb_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
+                                                             int capPerFrame, int* __restrict__ nOut,
+                                                             int* __restrict__ error) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_raw[DESC_WAVES][RAW_N * RAW_P];
+    __shared__ __attribute__((aligned(16))) uint16_t s_hb[DESC_WAVES][RAW_N * HB_P];
+    __shared__ __attribute__((aligned(16))) uint8_t s_bl[DESC_WAVES][BL_N * BL_P];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int outCapFrame = g->outCapFrame, nlevels = g->nlevels;
+    const int64_t slotGlobal = (int64_t)blockIdx.x * DESC_WAVES + wave;
+    if (slotGlobal >= (int64_t)nframes * outCapFrame) return;
+    const int frame = (int)(slotGlobal / outCapFrame);
+    const int slot = (int)(slotGlobal - (int64_t)frame * outCapFrame);
+    int level = 0;
+    for (int l = 1; l < nlevels; l++)
+        if (slot >= g->lv[l].outBase) level = l;
+    const OrbLevel& L = g->lv[level];
+    const int i = slot - L.outBase;
+    const int* lc = levelCount + frame * nlevels;
+    int before = 0, total = 0;
+    for (int l = 0; l < nlevels; l++) {
+        const int cnt = lc[l];
+        if (l < level) before += cnt;
+        total += cnt;
+    }
+    if (slot == 0 && lane == 0) {
+        nOut[frame] = total;
+        if (total > capPerFrame) atomicOr(error, 64);  // caller's buffers too small: reported, rows beyond cap dropped
+    }
+    if (i >= lc[level]) return;
+    const int outIdx = before + i;
+    if (outIdx >= capPerFrame) return;
+
+    const uint32_t xy = selXY[(int64_t)frame * outCapFrame + slot];
+    const int score = selScore[(int64_t)frame * outCapFrame + slot];
+    const int px = (int)(xy & 0xffff) + ORB_BORDER, py = (int)(xy >> 16) + ORB_BORDER;  // :885-886
+
+    const uint8_t* img;
+    int pitch;
+    if (level == 0) {
+        img = img0 + (int64_t)frame * frameStride0;
+        pitch = stride0;
+    } else {
+        img = pyr + L.off + (int64_t)frame * L.frameStride;
+        pitch = L.pitch;
+    }
+    uint8_t* raw = s_raw[wave];
+    uint16_t* hb = s_hb[wave];
+    uint8_t* bl = s_bl[wave];
+
+    // 43x43 source window, reflected at the level's borders like the blur's BORDER_REFLECT_101.
+    for (int k = lane; k < RAW_N * RAW_N; k += 64) {
+        const int r = k / RAW_N, c = k - r * RAW_N;
+        const int sx = reflect101(px - 21 + c, L.w), sy = reflect101(py - 21 + r, L.h);
+        raw[r * RAW_P + c] = img[(int64_t)sy * pitch + sx];
+    }
+    wave_lds_sync();
+
+    // Intensity centroid over the circular patch (rows v, half-width umax[|v|]).
+    const unsigned long long um = g->umaxPacked;
+    int m10 = 0, m01 = 0;
+    for (int k = lane; k < 31 * 31; k += 64) {
+        const int r = k / 31, v = r - 15, u = k - r * 31 - 15;
+        const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
+        const int lim = (int)((um >> (4 * av)) & 15ull);
+        if (au <= lim) {
+            const int val = raw[(21 + v) * RAW_P + 21 + u];
+            m10 += u * val;
+            m01 += v * val;
+        }
+    }
+    m10 = wave_sum(m10);
+    m01 = wave_sum(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // Blur of the 37x37 window: horizontal 8.8 sums, then vertical with one rounding.
+    const bool legacy = (g->quirks & ORB_Q_GAUSS_LEGACY) != 0;
+    const int k0 = 18, k1 = 34, k2 = legacy ? 49 : 48, k3 = legacy ? 55 : 56;
+    for (int k = lane; k < RAW_N * BL_N; k += 64) {
+        const int r = k / BL_N, c = k - r * BL_N;
+        const uint8_t* p = &raw[r * RAW_P + c];
+        hb[r * HB_P + c] = (uint16_t)(k0 * (p[0] + p[6]) + k1 * (p[1] + p[5]) + k2 * (p[2] + p[4]) + k3 * p[3]);
+    }
+    wave_lds_sync();
+    for (int k = lane; k < BL_N * BL_N; k += 64) {
+        const int r = k / BL_N, c = k - r * BL_N;
+        const uint16_t* p = &hb[r * HB_P + c];
+        uint32_t v = (uint32_t)k0 * (p[0] + p[6 * HB_P]) + (uint32_t)k1 * (p[HB_P] + p[5 * HB_P]) +
+                     (uint32_t)k2 * (p[2 * HB_P] + p[4 * HB_P]) + (uint32_t)k3 * p[3 * HB_P];
+        v = (v + 32768u) >> 16;
+        bl[r * BL_P + c] = (uint8_t)(v > 255u ? 255u : v);
+    }
+    wave_lds_sync();
+
+    // rBRIEF: lane l of round r compares pair 64r + l; the ballot is descriptor bytes 8r..8r+7.
+    const float factorPI = (float)(3.14159265358979323846 / 180.f);
+    float a, b;
+    sincos_portable(__fmul_rn(angle, factorPI), &b, &a);
+    unsigned long long words[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int pair = 64 * r + lane;
+        const float x0 = (float)c_pattern[4 * pair + 0], y0 = (float)c_pattern[4 * pair + 1];
+        const float x1 = (float)c_pattern[4 * pair + 2], y1 = (float)c_pattern[4 * pair + 3];
+        const int dy0 = (int)rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        const int dx0 = (int)rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        const int dy1 = (int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        const int dx1 = (int)rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        const int t0 = bl[(18 + dy0) * BL_P + 18 + dx0];
+        const int t1 = bl[(18 + dy1) * BL_P + 18 + dx1];
+        words[r] = __ballot(t0 < t1);
+    }
+    if (lane == 0) {
+        const int64_t o = (int64_t)frame * capPerFrame + outIdx;
+        unsigned long long* d = (unsigned long long*)(desc + o * 32);
+        d[0] = words[0];
+        d[1] = words[1];
+        d[2] = words[2];
+        d[3] = words[3];
+        orb_keypoint kp;
+        kp.x = __fmul_rn((float)px, L.scale);   // level 0: scale is 1
+        kp.y = __fmul_rn((float)py, L.scale);
+        kp.size = L.patchSize;
+        kp.angle = angle;
+        kp.response = (float)score;
+        kp.octave = level;
+        kp.class_id = -1;
+        kps[o] = kp;
+    }
+}
+
+int orb_launch_describe(const OrbBatch& b) {
+    const OrbGeom& g = *b.h_geom;
+    const int64_t slots = (int64_t)b.nframes * g.outCapFrame;
+    const int64_t blocks = (slots + DESC_WAVES - 1) / DESC_WAVES;
+    hipLaunchKernelGGL(k_describe, dim3((unsigned)blocks), dim3(64 * DESC_WAVES), 0, (hipStream_t)b.stream, b.d_geom,
+                       b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.nframes, b.d_selXY, b.d_selScore,
+                       b.d_levelCount, b.d_kps, b.d_desc, b.capPerFrame, b.d_nOut, b.d_error);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        orb_set_error("describe launch failed: %s", hipGetErrorString(e));
+        return ORB_ERR_HIP;
+    }
+    return ORB_OK;
+}

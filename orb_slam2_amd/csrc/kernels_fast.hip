@@ -1,0 +1,204 @@
+// Per-cell FAST-9 detection (the cell loop of
+// ORBextractor::ComputeKeyPointsOctTree, src/ORBextractor.cc:816-870, with
+// cv::FAST(.., nonmaxSuppression=true) inside) for gfx950.
+//
+// One wavefront owns one 30-pixel-class cell.  The reference runs cv::FAST on
+// the cell's ROI with iniThFAST and, if that finds nothing, again with
+// minThFAST.  cv::FAST's corner score is the largest threshold at which the
+// pixel is still a corner, independent of the threshold it was called with, and
+// its non-maximum suppression only sees scores inside the ROI's interior.  So
+// one score map t* per cell serves both calls:
+//   corner@th  <=>  t* >= th
+//   kept@th    <=>  t* >= th  and  t* > t*(q) for the 8 neighbours q inside the interior
+// and the interiors of the cells tile the level without overlap.
+//
+// Steps per cell: (1) stage the interior + 3-pixel halo in LDS, (2) t* for every
+// interior pixel into an LDS score tile with a zero rim, (3) local-maximum test,
+// ballot + prefix popcount for row-major ordered compaction (the order cv::FAST
+// emits), with the ini/min choice made after counting.
+#include <hip/hip_runtime.h>
+
+#include "orb_internal.h"
+
+#define FAST_WAVES 4
+#define TILE_PITCH 72                                   // >= 59 + 6, multiple of 4
+#define TILE_ROWS 66                                    // >= 59 + 6
+#define SCORE_PITCH 64                                  // >= 59 + 2
+#define SCORE_ROWS 62                                   // >= 59 + 2
+
+static __device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wavefront execute in issue order; this only stops the
+    // compiler from moving LDS accesses across the point and drains the counter.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+static __device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b, c)); }
+static __device__ __forceinline__ int imax3(int a, int b, int c) { return max(a, max(b, c)); }
+
+// t* = max(A, B) - 1 with A = max over the 16 arcs of 9 contiguous ring pixels
+// of min(v - ring), B likewise for (ring - v)   (cv::cornerScore<16>).
+static __device__ __forceinline__ int fast_score(const uint8_t* c) {
+    // c points at the centre inside the LDS tile
+    const int v = c[0];
+    int d[16];
+    d[0] = v - c[3 * TILE_PITCH + 0];
+    d[1] = v - c[3 * TILE_PITCH + 1];
+    d[2] = v - c[2 * TILE_PITCH + 2];
+    d[3] = v - c[1 * TILE_PITCH + 3];
+    d[4] = v - c[0 * TILE_PITCH + 3];
+    d[5] = v - c[-1 * TILE_PITCH + 3];
+    d[6] = v - c[-2 * TILE_PITCH + 2];
+    d[7] = v - c[-3 * TILE_PITCH + 1];
+    d[8] = v - c[-3 * TILE_PITCH + 0];
+    d[9] = v - c[-3 * TILE_PITCH - 1];
+    d[10] = v - c[-2 * TILE_PITCH - 2];
+    d[11] = v - c[-1 * TILE_PITCH - 3];
+    d[12] = v - c[0 * TILE_PITCH - 3];
+    d[13] = v - c[1 * TILE_PITCH - 3];
+    d[14] = v - c[2 * TILE_PITCH - 2];
+    d[15] = v - c[3 * TILE_PITCH - 1];
+    int lo3[16], hi3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lo3[k] = imin3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+        hi3[k] = imax3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    }
+    int A = -256, Bn = 256;  // Bn = min over arcs of max(d) = -B
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        A = max(A, imin3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
+        Bn = min(Bn, imax3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
+    }
+    return max(A, -Bn) - 1;
+}
+
+__global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(const OrbGeom* __restrict__ g,
+                                                               const uint8_t* __restrict__ img0, int stride0,
+                                                               int64_t frameStride0, const uint8_t* __restrict__ pyr,
+                                                               int nframes, uint32_t* __restrict__ cellKeys,
+                                                               int* __restrict__ cellCount) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[FAST_WAVES][TILE_ROWS * TILE_PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t s_score[FAST_WAVES][SCORE_ROWS * SCORE_PITCH];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t cellGlobal = (int64_t)blockIdx.x * FAST_WAVES + wave;
+    const int cellsPerFrame = g->cellsPerFrame;
+    if (cellGlobal >= (int64_t)nframes * cellsPerFrame) return;  // whole wave leaves; no workgroup barrier below
+    const int frame = (int)(cellGlobal / cellsPerFrame);
+    const int c = (int)(cellGlobal - (int64_t)frame * cellsPerFrame);
+    int level = 0;
+    for (int l = 1; l < g->nlevels; l++)
+        if (c >= g->lv[l].cellBase) level = l;
+    const OrbLevel& L = g->lv[level];
+    const int ci = c - L.cellBase;
+    const int i = ci / L.nCols, j = ci - i * L.nCols;
+
+    // Cell ROI and interior, src/ORBextractor.cc:825-844 (note the 3 / 6 asymmetry of the skip tests).
+    const int iniY = ORB_BORDER + i * L.hCell, iniX = ORB_BORDER + j * L.wCell;
+    int maxY = iniY + L.hCell + 6, maxX = iniX + L.wCell + 6;
+    if (maxY > L.maxBorderY) maxY = L.maxBorderY;
+    if (maxX > L.maxBorderX) maxX = L.maxBorderX;
+    const int X0 = iniX + 3, Y0 = iniY + 3;
+    int cw = maxX - 3 - X0, ch = maxY - 3 - Y0;
+    if (iniY >= L.maxBorderY - 3 || iniX >= L.maxBorderX - 6) cw = 0;
+    if (cw <= 0 || ch <= 0) {
+        if (lane == 0) cellCount[cellGlobal] = 0;
+        return;
+    }
+
+    const uint8_t* img;
+    int pitch;
+    if (level == 0) {
+        img = img0 + (int64_t)frame * frameStride0;
+        pitch = stride0;
+    } else {
+        img = pyr + L.off + (int64_t)frame * L.frameStride;
+        pitch = L.pitch;
+    }
+    uint8_t* tile = s_tile[wave];
+    uint8_t* score = s_score[wave];
+
+    // (1) interior + halo -> LDS; zero the score tile.
+    const int tw = cw + 6, th = ch + 6;
+    const uint8_t* src = img + (int64_t)(Y0 - 3) * pitch + (X0 - 3);
+    for (int r = 0; r < th; r++) {
+        for (int x = lane; x < tw; x += 64) tile[r * TILE_PITCH + x] = src[(int64_t)r * pitch + x];
+    }
+    {
+        uint32_t* s32 = (uint32_t*)score;
+        for (int k = lane; k < SCORE_ROWS * SCORE_PITCH / 4; k += 64) s32[k] = 0u;
+    }
+    wave_lds_sync();
+
+    // (2) scores.  Cells up to 32 wide are walked two rows per step.
+    const int minTh = g->minTh, iniTh = g->iniTh;
+    const int two = cw <= 32;
+    const int ly = two ? (lane >> 5) : 0, lx = two ? (lane & 31) : lane;
+    const int rowsPerStep = two ? 2 : 1;
+    const int steps = (ch + rowsPerStep - 1) / rowsPerStep;
+    for (int p = 0; p < steps; p++) {
+        const int y = p * rowsPerStep + ly;
+        if (lx < cw && y < ch) {
+            const int t = fast_score(&tile[(y + 3) * TILE_PITCH + lx + 3]);
+            score[(y + 1) * SCORE_PITCH + lx + 1] = (uint8_t)(t >= minTh ? t : 0);
+        }
+    }
+    wave_lds_sync();
+
+    // (3) local maxima, counted for both thresholds; per-lane bit p remembers step p.
+    unsigned long long keepIni = 0ull, keepMin = 0ull;
+    int cntIni = 0, cntMin = 0;
+    for (int p = 0; p < steps; p++) {
+        const int y = p * rowsPerStep + ly;
+        bool lm = false, li = false;
+        if (lx < cw && y < ch) {
+            const uint8_t* sp = &score[(y + 1) * SCORE_PITCH + lx + 1];
+            const int s = sp[0];
+            if (s > 0) {
+                const int nb = max(max(imax3(sp[-SCORE_PITCH - 1], sp[-SCORE_PITCH], sp[-SCORE_PITCH + 1]),
+                                       imax3(sp[SCORE_PITCH - 1], sp[SCORE_PITCH], sp[SCORE_PITCH + 1])),
+                                   max((int)sp[-1], (int)sp[1]));
+                lm = s > nb;
+                li = lm && s >= iniTh;
+            }
+        }
+        keepMin |= (unsigned long long)lm << p;
+        keepIni |= (unsigned long long)li << p;
+        cntMin += __popcll(__ballot(lm));
+        cntIni += __popcll(__ballot(li));
+    }
+    const unsigned long long keep = cntIni > 0 ? keepIni : keepMin;  // fallback decided after suppression, :852
+    const int total = cntIni > 0 ? cntIni : cntMin;
+    const int cellCap = g->cellCap;
+    uint32_t* out = cellKeys + cellGlobal * cellCap;
+    int run = 0;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int p = 0; p < steps; p++) {
+        const bool f = (keep >> p) & 1ull;
+        const unsigned long long b = __ballot(f);
+        if (f) {
+            const int y = p * rowsPerStep + ly;
+            const int pos = run + __popcll(b & below);
+            const int s = score[(y + 1) * SCORE_PITCH + lx + 1];
+            if (pos < cellCap) out[pos] = (uint32_t)lx | ((uint32_t)y << 8) | ((uint32_t)s << 16);
+        }
+        run += __popcll(b);
+    }
+    if (lane == 0) cellCount[cellGlobal] = total;  // total <= cellCap by the 2x2-block bound on strict local maxima
+}
+
+int orb_launch_fast(const OrbBatch& b) {
+    const OrbGeom& g = *b.h_geom;
+    const int64_t cells = (int64_t)b.nframes * g.cellsPerFrame;
+    const int64_t blocks = (cells + FAST_WAVES - 1) / FAST_WAVES;
+    hipLaunchKernelGGL(k_fast_cells, dim3((unsigned)blocks), dim3(64 * FAST_WAVES), 0, (hipStream_t)b.stream, b.d_geom,
+                       b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.nframes, b.d_cellKeys, b.d_cellCount);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        orb_set_error("fast launch failed: %s", hipGetErrorString(e));
+        return ORB_ERR_HIP;
+    }
+    return ORB_OK;
+}

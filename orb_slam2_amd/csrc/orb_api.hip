@@ -1,0 +1,800 @@
+// Host side of liborbhip: context, level geometry, resize tap tables, buffer
+// management and the extraction entry points of include/orb_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "orb_internal.h"
+
+// ---- error reporting ----------------------------------------------------------------
+static thread_local char t_err[512] = "";
+
+void orb_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_err, sizeof(t_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* orb_last_error(void) { return t_err; }
+extern "C" const char* orb_version(void) { return "orbhip 0.1 (gfx950)"; }
+
+#define HIP_TRY(call)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            orb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return ORB_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+static inline int cv_round(float v) { return (int)lrintf(v); }
+static inline int cv_floor(double v) {
+    int i = (int)v;
+    return i - (i > v);
+}
+static inline int cv_ceil(double v) {
+    int i = (int)v;
+    return i + (i < v);
+}
+
+// ---- context --------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return ORB_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&p, need);
+        if (e != hipSuccess) {
+            orb_set_error("hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+            return ORB_ERR_NOMEM;
+        }
+        bytes = need;
+        return ORB_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct orb_ctx {
+    orb_params prm;
+    double scaleFactorD;  // the reference keeps scaleFactor in a double member (include/ORBextractor.h:88)
+    std::vector<float> scale, invScale, sigma2, invSigma2;
+    std::vector<int> perLevel;
+    int umax[16];
+    OrbGeom geom;          // for the current frame size
+    bool geomValid = false;
+    std::vector<OrbAreaTap> areaTaps;
+    std::vector<OrbLinTap> linTaps;
+    hipStream_t stream = nullptr;
+    DevBuf dGeom, dAreaTaps, dLinTaps, dInput, dPyr, dCellKeys, dCellCount, dCellOff, dSort, dInfo, dNodes, dInts,
+        dSelXY, dSelScore, dLevelCount, dLevelKeys, dError, dKps, dDesc, dNOut, dTmpA, dTmpB;
+    int lastFrames = 0;
+    int inputStride = 0;
+    const uint8_t* lastImg0 = nullptr;
+    int lastStride0 = 0;
+    int64_t lastFrameStride0 = 0;
+    // matcher scratch lives in kernels_match.hip
+    void* matchState = nullptr;
+};
+
+void orb_match_state_free(void* p);
+
+// accessors for the matcher's translation unit
+int orb_ctx_device(const orb_ctx* c) { return c->prm.device; }
+unsigned orb_ctx_quirks(const orb_ctx* c) { return c->prm.quirks; }
+int orb_ctx_max_batch(const orb_ctx* c) { return c->prm.max_batch; }
+void** orb_ctx_match_state(orb_ctx* c) { return &c->matchState; }
+
+// ORBextractor::ORBextractor, src/ORBextractor.cc:369-436 (inverse tables divide by the forward tables).
+static int build_tables(orb_ctx* c) {
+    const orb_params& p = c->prm;
+    const int L = p.nlevels;
+    c->scaleFactorD = (double)p.scale_factor;
+    c->scale.assign(L, 1.f);
+    c->sigma2.assign(L, 1.f);
+    for (int i = 1; i < L; i++) {
+        c->scale[i] = (float)(c->scale[i - 1] * c->scaleFactorD);
+        c->sigma2[i] = c->scale[i] * c->scale[i];
+    }
+    c->invScale.resize(L);
+    c->invSigma2.resize(L);
+    for (int i = 0; i < L; i++) {
+        c->invScale[i] = 1.0f / c->scale[i];
+        c->invSigma2[i] = 1.0f / c->sigma2[i];
+    }
+    c->perLevel.assign(L, 0);
+    const float factor = (float)(1.0f / c->scaleFactorD);
+    float nDesired = p.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)L));
+    int sum = 0;
+    for (int l = 0; l < L - 1; l++) {
+        c->perLevel[l] = cv_round(nDesired);
+        sum += c->perLevel[l];
+        nDesired *= factor;
+    }
+    c->perLevel[L - 1] = std::max(p.nfeatures - sum, 0);
+    // patch row half-widths, :420-435
+    for (int i = 0; i < 16; i++) c->umax[i] = 0;
+    const int HALF = 15;
+    const int vmax = cv_floor(HALF * sqrt(2.f) / 2 + 1);
+    const int vmin = cv_ceil(HALF * sqrt(2.f) / 2);
+    const double hp2 = HALF * HALF;
+    int v, v0;
+    for (v = 0; v <= vmax; ++v) c->umax[v] = (int)lrint(sqrt(hp2 - v * v));
+    for (v = HALF, v0 = 0; v >= vmin; --v) {
+        if (p.quirks & ORB_Q_UMAX_FORK) {
+            while (c->umax[v] == c->umax[v0 + 1]) ++v0;
+        } else {
+            while (c->umax[v0] == c->umax[v0 + 1]) ++v0;
+        }
+        c->umax[v] = v0;
+        ++v0;
+    }
+    return ORB_OK;
+}
+
+// cv::resize(INTER_AREA) per-axis table (computeResizeAreaTab): covered source cells and fractions.
+static int area_taps(int ssize, int dsize, std::vector<OrbAreaTap>& out) {
+    const double scale = 1. / ((double)dsize / ssize);
+    if (!(scale >= 1.0)) {
+        orb_set_error("area resize needs a shrinking level ratio (got %f)", scale);
+        return ORB_ERR_UNSUPPORTED;
+    }
+    if (std::fabs(scale - (int)scale) < 2.220446049250313e-16) {
+        orb_set_error("level ratio %d:%d is an exact integer; cv::resize takes a different INTER_AREA path there", ssize,
+                      dsize);
+        return ORB_ERR_UNSUPPORTED;
+    }
+    for (int d = 0; d < dsize; d++) {
+        OrbAreaTap t;
+        memset(&t, 0, sizeof(t));
+        int k = 0;
+        const double f1 = d * scale, f2 = f1 + scale;
+        const double cell = std::min(scale, ssize - f1);
+        int s1 = cv_ceil(f1), s2 = cv_floor(f2);
+        s2 = std::min(s2, ssize - 1);
+        s1 = std::min(s1, s2);
+        auto push = [&](int si, float a) -> bool {
+            if (k >= ORB_MAX_TAPS) return false;
+            t.si[k] = si;
+            t.a[k] = a;
+            k++;
+            return true;
+        };
+        bool ok = true;
+        if (s1 - f1 > 1e-3) ok = ok && push(s1 - 1, (float)((s1 - f1) / cell));
+        for (int s = s1; s < s2; s++) ok = ok && push(s, (float)(1.0 / cell));
+        if (f2 - s2 > 1e-3) ok = ok && push(s2, (float)(std::min(std::min(f2 - s2, 1.), cell) / cell));
+        if (!ok) {
+            orb_set_error("scale factor too large: more than %d source cells per destination pixel", ORB_MAX_TAPS);
+            return ORB_ERR_UNSUPPORTED;
+        }
+        out.push_back(t);
+    }
+    return ORB_OK;
+}
+
+// cv::resize(INTER_LINEAR) per-axis table: source index pair and 11-bit weights.
+static void linear_taps(int ssize, int dsize, bool clampWeights, std::vector<OrbLinTap>& out) {
+    const double scale = 1. / ((double)dsize / ssize);
+    auto sat16 = [](int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); };
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = cv_floor(f);
+        f -= s;
+        OrbLinTap t;
+        if (clampWeights) {  // horizontal: out-of-range taps get weight 0
+            if (s < 0) f = 0, s = 0;
+            if (s >= ssize - 1) f = 0, s = ssize - 1;
+            t.s0 = s;
+            t.s1 = std::min(s + 1, ssize - 1);
+        } else {  // vertical: rows are clamped, weights kept
+            t.s0 = std::min(std::max(s, 0), ssize - 1);
+            t.s1 = std::min(std::max(s + 1, 0), ssize - 1);
+        }
+        t.a0 = sat16(cv_round((1.f - f) * 2048));
+        t.a1 = sat16(cv_round(f * 2048));
+        out.push_back(t);
+    }
+}
+
+static inline int halfUp(int v) { return (v + 1) >> 1; }
+
+// Level sizes (src/ORBextractor.cc:917-918), FAST cell grid (:808-823), quadtree
+// roots (:574-576) and every derived capacity for a w x h frame.
+static int compute_geom(orb_ctx* c, int w, int h) {
+    if (c->geomValid && c->geom.w == w && c->geom.h == h) return ORB_OK;
+    const orb_params& p = c->prm;
+    OrbGeom g;
+    memset(&g, 0, sizeof(g));
+    g.nlevels = p.nlevels;
+    g.w = w;
+    g.h = h;
+    g.iniTh = std::min(std::max(p.ini_th_fast, 0), 255);
+    g.minTh = std::min(std::max(p.min_th_fast, 0), 255);
+    g.quirks = p.quirks;
+    g.umaxPacked = 0;
+    for (int i = 0; i < 16; i++) g.umaxPacked |= (unsigned long long)(c->umax[i] & 15) << (4 * i);
+    std::vector<OrbAreaTap> at;
+    std::vector<OrbLinTap> lt;
+    int64_t pyrOff = 0;
+    int cellBase = 0, outBase = 0, cellCap = 1;
+    int64_t keyBase = 0, nodeBase = 0;
+    for (int l = 0; l < p.nlevels; l++) {
+        OrbLevel& L = g.lv[l];
+        const float sc = c->invScale[l];
+        L.w = cv_round((float)w * sc);
+        L.h = cv_round((float)h * sc);
+        L.pitch = (L.w + 63) & ~63;
+        L.frameStride = (int64_t)L.pitch * L.h;
+        L.off = pyrOff;  // multiplied by the batch size at launch time (levels are stored level-major)
+        if (l > 0) pyrOff += L.frameStride;
+        L.maxBorderX = L.w - ORB_EDGE + 3;
+        L.maxBorderY = L.h - ORB_EDGE + 3;
+        const float width = (float)(L.maxBorderX - ORB_BORDER), height = (float)(L.maxBorderY - ORB_BORDER);
+        L.nCols = (int)(width / 30.f);
+        L.nRows = (int)(height / 30.f);
+        if (L.nCols < 1 || L.nRows < 1) {
+            orb_set_error("level %d of a %dx%d frame is %dx%d: smaller than one 30-pixel FAST cell plus borders", l, w,
+                          h, L.w, L.h);
+            return ORB_ERR_UNSUPPORTED;
+        }
+        L.wCell = (int)ceilf(width / L.nCols);
+        L.hCell = (int)ceilf(height / L.nRows);
+        if (L.wCell > 59 || L.hCell > 59) {
+            orb_set_error("internal: cell %dx%d exceeds the kernel tile", L.wCell, L.hCell);
+            return ORB_ERR_UNSUPPORTED;
+        }
+        L.cellBase = cellBase;
+        cellBase += L.nCols * L.nRows;
+        L.nIni = (int)lroundf((float)(L.maxBorderX - ORB_BORDER) / (L.maxBorderY - ORB_BORDER));
+        if (L.nIni < 1 || L.nIni > 16) {
+            orb_set_error("aspect ratio of level %d (%dx%d) gives %d quadtree roots; supported 1..16", l, L.w, L.h,
+                          L.nIni);
+            return ORB_ERR_UNSUPPORTED;
+        }
+        L.hX = (float)(L.maxBorderX - ORB_BORDER) / L.nIni;
+        L.quota = c->perLevel[l];
+        L.outCap = std::max(L.quota + 3, 4 * L.nIni);
+        L.outBase = outBase;
+        outBase += L.outCap;
+        L.nodeCap = L.outCap + 8;
+        L.nodeBase = nodeBase;
+        nodeBase += L.nodeCap;
+        // most keys FAST can emit: strict local maxima take at most one pixel of every 2x2 block of a cell interior
+        int64_t keys = 0;
+        for (int i = 0; i < L.nRows; i++) {
+            const int iniY = ORB_BORDER + i * L.hCell;
+            if (iniY >= L.maxBorderY - 3) continue;
+            const int maxY = std::min(iniY + L.hCell + 6, L.maxBorderY);
+            const int ch = maxY - 3 - (iniY + 3);
+            if (ch <= 0) continue;
+            for (int j = 0; j < L.nCols; j++) {
+                const int iniX = ORB_BORDER + j * L.wCell;
+                if (iniX >= L.maxBorderX - 6) continue;
+                const int maxX = std::min(iniX + L.wCell + 6, L.maxBorderX);
+                const int cw = maxX - 3 - (iniX + 3);
+                if (cw <= 0) continue;
+                const int cap = halfUp(cw) * halfUp(ch);
+                keys += cap;
+                cellCap = std::max(cellCap, cap);
+            }
+        }
+        if (keys > 0x7fffffff) {
+            orb_set_error("frame too large");
+            return ORB_ERR_UNSUPPORTED;
+        }
+        L.keyCap = (int)keys;
+        L.keyBase = keyBase;
+        keyBase += keys;
+        L.scale = c->scale[l];
+        L.patchSize = (float)(int)(31 * c->scale[l]);  // :881, int * float truncated
+        L.tabX = L.tabY = 0;
+        if (l > 0) {
+            const OrbLevel& P = g.lv[l - 1];
+            if (p.quirks & ORB_Q_RESIZE_AREA) {
+                L.tabX = (int)at.size();
+                int rc = area_taps(P.w, L.w, at);
+                if (rc) return rc;
+                L.tabY = (int)at.size();
+                rc = area_taps(P.h, L.h, at);
+                if (rc) return rc;
+            } else {
+                if (P.w == 2 * L.w && P.h == 2 * L.h) {
+                    orb_set_error("exact 2:1 level ratio: cv::resize(INTER_LINEAR) switches to INTER_AREA there");
+                    return ORB_ERR_UNSUPPORTED;
+                }
+                L.tabX = (int)lt.size();
+                linear_taps(P.w, L.w, true, lt);
+                L.tabY = (int)lt.size();
+                linear_taps(P.h, L.h, false, lt);
+            }
+        }
+    }
+    // quadtree path digits must reach single pixels: 2^ORB_CODE_DEPTH-1 >= larger border-relative extent
+    if (std::max(w, h) - 2 * ORB_BORDER > (1 << (ORB_CODE_DEPTH - 1))) {
+        orb_set_error("frame side %d exceeds the %d-pixel limit of the quadtree path code", std::max(w, h),
+                      (1 << (ORB_CODE_DEPTH - 1)) + 2 * ORB_BORDER);
+        return ORB_ERR_UNSUPPORTED;
+    }
+    g.cellsPerFrame = cellBase;
+    g.cellCap = cellCap;
+    g.outCapFrame = outBase;
+    g.keysPerFrame = keyBase;
+    g.nodesPerFrame = nodeBase;
+    c->geom = g;
+    c->areaTaps.swap(at);
+    c->linTaps.swap(lt);
+    c->geomValid = true;
+    c->lastFrames = 0;  // per-batch level offsets must be rebuilt
+    int rc;
+    if ((rc = c->dGeom.ensure(sizeof(OrbGeom)))) return rc;
+    if ((rc = c->dAreaTaps.ensure(std::max<size_t>(1, c->areaTaps.size()) * sizeof(OrbAreaTap)))) return rc;
+    if ((rc = c->dLinTaps.ensure(std::max<size_t>(1, c->linTaps.size()) * sizeof(OrbLinTap)))) return rc;
+    // (synchronous copies: geometry only changes when the frame size does)
+    HIP_TRY(hipDeviceSynchronize());
+    if (!c->areaTaps.empty())
+        HIP_TRY(hipMemcpy(c->dAreaTaps.p, c->areaTaps.data(), c->areaTaps.size() * sizeof(OrbAreaTap),
+                          hipMemcpyHostToDevice));
+    if (!c->linTaps.empty())
+        HIP_TRY(hipMemcpy(c->dLinTaps.p, c->linTaps.data(), c->linTaps.size() * sizeof(OrbLinTap),
+                          hipMemcpyHostToDevice));
+    return ORB_OK;
+}
+
+// Pyramid levels are stored level-major: all frames of level 1, then level 2, ...
+// so the per-level offsets depend on the batch size; the device copy of the
+// geometry is refreshed when either changes.
+static int finalize_geom_for_batch(orb_ctx* c, int nframes) {
+    OrbGeom& g = c->geom;
+    if (c->lastFrames == nframes) return ORB_OK;
+    int64_t off = 0;
+    for (int l = 1; l < g.nlevels; l++) {
+        g.lv[l].off = off;
+        off += g.lv[l].frameStride * nframes;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(c->dGeom.p, &g, sizeof(OrbGeom), hipMemcpyHostToDevice));
+    c->lastFrames = nframes;
+    return ORB_OK;
+}
+
+static int ensure_buffers(orb_ctx* c, int n) {
+    const OrbGeom& g = c->geom;
+    int rc;
+    int64_t pyr = 0;
+    for (int l = 1; l < g.nlevels; l++) pyr += g.lv[l].frameStride * n;
+    if ((rc = c->dPyr.ensure((size_t)std::max<int64_t>(pyr, 64)))) return rc;
+    if ((rc = c->dCellKeys.ensure((size_t)n * g.cellsPerFrame * g.cellCap * 4))) return rc;
+    if ((rc = c->dCellCount.ensure((size_t)n * g.cellsPerFrame * 4))) return rc;
+    if ((rc = c->dCellOff.ensure((size_t)n * (g.cellsPerFrame + g.nlevels) * 4))) return rc;
+    if ((rc = c->dSort.ensure((size_t)n * g.keysPerFrame * 8 + 8))) return rc;
+    if ((rc = c->dInfo.ensure((size_t)n * g.keysPerFrame * 8 + 8))) return rc;
+    if ((rc = c->dNodes.ensure((size_t)n * g.nodesPerFrame * 2 * sizeof(OrbNode)))) return rc;
+    if ((rc = c->dInts.ensure(((size_t)n * g.nodesPerFrame * 9 + (size_t)n * g.nlevels * 4) * 4))) return rc;
+    if ((rc = c->dSelXY.ensure((size_t)n * g.outCapFrame * 4))) return rc;
+    if ((rc = c->dSelScore.ensure((size_t)n * g.outCapFrame * 4))) return rc;
+    if ((rc = c->dLevelCount.ensure((size_t)n * g.nlevels * 4))) return rc;
+    if ((rc = c->dLevelKeys.ensure((size_t)n * g.nlevels * 4))) return rc;
+    if (!c->dError.p) {
+        if ((rc = c->dError.ensure(4))) return rc;
+        HIP_TRY(hipMemset(c->dError.p, 0, 4));
+    }
+    return ORB_OK;
+}
+
+extern "C" int orb_create(const orb_params* prm, orb_ctx** out) {
+    if (!prm || !out) {
+        orb_set_error("orb_create: null argument");
+        return ORB_ERR_INVALID;
+    }
+    *out = nullptr;
+    if (prm->nlevels < 1 || prm->nlevels > ORB_MAX_LEVELS) {
+        orb_set_error("nlevels %d outside 1..%d", prm->nlevels, ORB_MAX_LEVELS);
+        return ORB_ERR_UNSUPPORTED;
+    }
+    if (prm->nfeatures < 1 || !(prm->scale_factor > 1.0f) || prm->max_batch < 1 || prm->max_width < 1 ||
+        prm->max_height < 1) {
+        orb_set_error("orb_create: nfeatures, max sizes and max_batch must be >= 1, scale_factor > 1");
+        return ORB_ERR_INVALID;
+    }
+    if (prm->min_th_fast < 1 || prm->ini_th_fast < prm->min_th_fast || prm->ini_th_fast > 255) {
+        orb_set_error("FAST thresholds must satisfy 1 <= minThFAST <= iniThFAST <= 255");
+        return ORB_ERR_UNSUPPORTED;
+    }
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (prm->device < 0 || prm->device >= ndev) {
+        orb_set_error("device %d not present (%d devices)", prm->device, ndev);
+        return ORB_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(prm->device));
+    orb_ctx* c = new (std::nothrow) orb_ctx();
+    if (!c) return ORB_ERR_NOMEM;
+    c->prm = *prm;
+    build_tables(c);
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // size everything for the largest announced frame and batch now, so steady-state calls allocate nothing
+    int rc = compute_geom(c, prm->max_width, prm->max_height);
+    if (rc == ORB_OK) rc = ensure_buffers(c, prm->max_batch);
+    if (rc == ORB_OK) {
+        const int cap = orb_max_keypoints_per_frame(c);
+        c->inputStride = (prm->max_width + 63) & ~63;
+        rc = c->dInput.ensure((size_t)prm->max_batch * c->inputStride * prm->max_height);
+        if (rc == ORB_OK) rc = c->dKps.ensure((size_t)prm->max_batch * cap * sizeof(orb_keypoint));
+        if (rc == ORB_OK) rc = c->dDesc.ensure((size_t)prm->max_batch * cap * 32);
+        if (rc == ORB_OK) rc = c->dNOut.ensure((size_t)prm->max_batch * 4);
+    }
+    if (rc != ORB_OK) {
+        orb_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return ORB_OK;
+}
+
+extern "C" void orb_destroy(orb_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->prm.device);
+    (void)hipDeviceSynchronize();
+    DevBuf* bufs[] = {&c->dGeom, &c->dAreaTaps, &c->dLinTaps, &c->dInput, &c->dPyr, &c->dCellKeys, &c->dCellCount,
+                      &c->dCellOff, &c->dSort, &c->dInfo, &c->dNodes, &c->dInts, &c->dSelXY, &c->dSelScore,
+                      &c->dLevelCount, &c->dLevelKeys, &c->dError, &c->dKps, &c->dDesc, &c->dNOut, &c->dTmpA,
+                      &c->dTmpB};
+    for (DevBuf* b : bufs) b->release();
+    if (c->matchState) orb_match_state_free(c->matchState);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int orb_max_keypoints_per_frame(const orb_ctx* c) {
+    if (!c) return 0;
+    // independent of the frame size except through the number of quadtree roots (at most 16)
+    int cap = 0;
+    for (int l = 0; l < c->prm.nlevels; l++) cap += std::max(c->perLevel[l] + 3, 4 * 16);
+    return cap;
+}
+
+extern "C" int orb_get_tables(const orb_ctx* c, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                              int* per_level, int* umax) {
+    if (!c) {
+        orb_set_error("null context");
+        return ORB_ERR_INVALID;
+    }
+    for (int i = 0; i < c->prm.nlevels; i++) {
+        if (scale) scale[i] = c->scale[i];
+        if (inv_scale) inv_scale[i] = c->invScale[i];
+        if (sigma2) sigma2[i] = c->sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = c->invSigma2[i];
+        if (per_level) per_level[i] = c->perLevel[i];
+    }
+    if (umax)
+        for (int i = 0; i < 16; i++) umax[i] = c->umax[i];
+    return ORB_OK;
+}
+
+// Enqueue the whole extraction for n frames whose level 0 is at d_img0.
+static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int stride, int64_t frameStride,
+                     orb_keypoint* d_kps, uint8_t* d_desc, int cap, int* d_nOut, hipStream_t st) {
+    if (n < 1 || n > c->prm.max_batch) {
+        orb_set_error("batch of %d frames outside 1..max_batch=%d", n, c->prm.max_batch);
+        return ORB_ERR_INVALID;
+    }
+    if (w > c->prm.max_width || h > c->prm.max_height) {
+        orb_set_error("frame %dx%d larger than the context's %dx%d", w, h, c->prm.max_width, c->prm.max_height);
+        return ORB_ERR_INVALID;
+    }
+    if (stride < w || cap < 1) {
+        orb_set_error("bad stride or capacity");
+        return ORB_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->prm.device));
+    int rc;
+    if ((rc = compute_geom(c, w, h))) return rc;
+    if ((rc = ensure_buffers(c, n))) return rc;
+    if ((rc = finalize_geom_for_batch(c, n))) return rc;
+    OrbBatch b;
+    memset(&b, 0, sizeof(b));
+    b.d_geom = (const OrbGeom*)c->dGeom.p;
+    b.h_geom = &c->geom;
+    b.d_img0 = d_img0;
+    b.stride0 = stride;
+    b.frameStride0 = frameStride;
+    b.nframes = n;
+    b.d_pyr = (uint8_t*)c->dPyr.p;
+    b.d_areaTaps = (const OrbAreaTap*)c->dAreaTaps.p;
+    b.d_linTaps = (const OrbLinTap*)c->dLinTaps.p;
+    b.d_cellKeys = (uint32_t*)c->dCellKeys.p;
+    b.d_cellCount = (int*)c->dCellCount.p;
+    b.d_cellOff = (int*)c->dCellOff.p;
+    b.d_sort = (unsigned long long*)c->dSort.p;
+    b.d_keyInfo = (unsigned long long*)c->dInfo.p;
+    b.d_nodes = (OrbNode*)c->dNodes.p;
+    b.d_ints = (int*)c->dInts.p;
+    b.d_selXY = (uint32_t*)c->dSelXY.p;
+    b.d_selScore = (int*)c->dSelScore.p;
+    b.d_levelCount = (int*)c->dLevelCount.p;
+    b.d_levelKeys = (int*)c->dLevelKeys.p;
+    b.d_error = (int*)c->dError.p;
+    b.d_kps = d_kps;
+    b.d_desc = d_desc;
+    b.capPerFrame = cap;
+    b.d_nOut = d_nOut;
+    b.stream = st;
+    c->lastImg0 = d_img0;
+    c->lastStride0 = stride;
+    c->lastFrameStride0 = frameStride;
+    if ((rc = orb_launch_pyramid(b))) return rc;
+    if ((rc = orb_launch_fast(b))) return rc;
+    if ((rc = orb_launch_quadtree(b))) return rc;
+    if ((rc = orb_launch_describe(b))) return rc;
+    return ORB_OK;
+}
+
+static int read_error_flag(orb_ctx* c) {
+    int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, c->dError.p, 4, hipMemcpyDeviceToHost));
+    if (flag) {
+        HIP_TRY(hipMemset(c->dError.p, 0, 4));
+        orb_set_error("extraction hit an internal limit (flags 0x%x:%s%s%s%s%s)", flag,
+                      (flag & 4) ? " key capacity" : "", (flag & 8) ? " node pool" : "",
+                      (flag & 16) ? " quadtree depth" : "", (flag & 32) ? " level output" : "",
+                      (flag & 64) ? " caller keypoint capacity" : "");
+        return ORB_ERR_CAPACITY;
+    }
+    return ORB_OK;
+}
+
+extern "C" int orb_check_last_batch(orb_ctx* c) {
+    if (!c) {
+        orb_set_error("null context");
+        return ORB_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->prm.device));
+    HIP_TRY(hipDeviceSynchronize());
+    return read_error_flag(c);
+}
+
+extern "C" int orb_extract_batch_device(orb_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int stride,
+                                        int64_t frame_stride, orb_keypoint* d_kps, uint8_t* d_desc, int cap_per_frame,
+                                        int* d_n_out, void* stream) {
+    if (!c || !d_imgs || !d_kps || !d_desc || !d_n_out) {
+        orb_set_error("orb_extract_batch_device: null argument");
+        return ORB_ERR_INVALID;
+    }
+    if (w <= 0 || h <= 0) {
+        orb_set_error("empty frames are not accepted by the device entry point");
+        return ORB_ERR_INVALID;
+    }
+    return run_batch(c, d_imgs, n, w, h, stride, frame_stride, d_kps, d_desc, cap_per_frame, d_n_out,
+                     (hipStream_t)stream);
+}
+
+extern "C" int orb_extract_batch(orb_ctx* c, const uint8_t* const* imgs, int n, int w, int h, int stride,
+                                 orb_keypoint* kps, uint8_t* desc, int cap_per_frame, int* n_out) {
+    if (!c || !imgs || !n_out) {
+        orb_set_error("orb_extract_batch: null argument");
+        return ORB_ERR_INVALID;
+    }
+    if (w <= 0 || h <= 0) {  // empty image: silent return, src/ORBextractor.cc:451-452
+        for (int f = 0; f < n; f++) n_out[f] = 0;
+        return ORB_OK;
+    }
+    if (n < 1 || n > c->prm.max_batch || w > c->prm.max_width || h > c->prm.max_height || stride < w) {
+        orb_set_error("orb_extract_batch: batch %d / frame %dx%d stride %d outside the context's limits", n, w, h,
+                      stride);
+        return ORB_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->prm.device));
+    int rc = compute_geom(c, w, h);
+    if (rc) return rc;
+    const int cap = orb_max_keypoints_per_frame(c);
+    const int dstride = c->inputStride;
+    const int64_t fstride = (int64_t)dstride * h;
+    for (int f = 0; f < n; f++) {
+        if (!imgs[f]) {
+            orb_set_error("frame %d is null", f);
+            return ORB_ERR_INVALID;
+        }
+        HIP_TRY(hipMemcpy2DAsync((uint8_t*)c->dInput.p + f * fstride, dstride, imgs[f], stride, w, h,
+                                 hipMemcpyHostToDevice, c->stream));
+    }
+    rc = run_batch(c, (const uint8_t*)c->dInput.p, n, w, h, dstride, fstride, (orb_keypoint*)c->dKps.p,
+                   (uint8_t*)c->dDesc.p, cap, (int*)c->dNOut.p, c->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(n_out, c->dNOut.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((rc = read_error_flag(c))) return rc;
+    for (int f = 0; f < n; f++) {
+        const int m = n_out[f];
+        if (m > cap_per_frame) {
+            orb_set_error("frame %d produced %d keypoints, caller capacity is %d", f, m, cap_per_frame);
+            return ORB_ERR_CAPACITY;
+        }
+        if (m > 0) {
+            if (kps)
+                HIP_TRY(hipMemcpyAsync(kps + (size_t)f * cap_per_frame, (orb_keypoint*)c->dKps.p + (size_t)f * cap,
+                                       (size_t)m * sizeof(orb_keypoint), hipMemcpyDeviceToHost, c->stream));
+            if (desc)
+                HIP_TRY(hipMemcpyAsync(desc + (size_t)f * cap_per_frame * 32, (uint8_t*)c->dDesc.p + (size_t)f * cap * 32,
+                                       (size_t)m * 32, hipMemcpyDeviceToHost, c->stream));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ORB_OK;
+}
+
+extern "C" int orb_extract(orb_ctx* c, const uint8_t* img, int w, int h, int stride, orb_keypoint* kps, uint8_t* desc,
+                           int cap, int* n_out) {
+    if (!n_out) {
+        orb_set_error("orb_extract: null n_out");
+        return ORB_ERR_INVALID;
+    }
+    if (!img || w <= 0 || h <= 0) {  // empty image: silent return, src/ORBextractor.cc:451-452
+        *n_out = 0;
+        return ORB_OK;
+    }
+    const uint8_t* one[1] = {img};
+    return orb_extract_batch(c, one, 1, w, h, stride, kps, desc, cap, n_out);
+}
+
+extern "C" int orb_get_pyramid_level(orb_ctx* c, int frame, int level, uint8_t* dst, int dst_stride, int* w, int* h) {
+    if (!c || !c->geomValid || !c->lastImg0) {
+        orb_set_error("no batch has been extracted yet");
+        return ORB_ERR_INVALID;
+    }
+    const OrbGeom& g = c->geom;
+    if (level < 0 || level >= g.nlevels || frame < 0 || frame >= c->lastFrames) {
+        orb_set_error("frame %d / level %d out of range", frame, level);
+        return ORB_ERR_INVALID;
+    }
+    const OrbLevel& L = g.lv[level];
+    if (w) *w = L.w;
+    if (h) *h = L.h;
+    if (!dst) return ORB_OK;
+    if (dst_stride < L.w) {
+        orb_set_error("dst_stride %d < level width %d", dst_stride, L.w);
+        return ORB_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->prm.device));
+    HIP_TRY(hipDeviceSynchronize());
+    const uint8_t* src;
+    int pitch;
+    if (level == 0) {
+        src = c->lastImg0 + (int64_t)frame * c->lastFrameStride0;
+        pitch = c->lastStride0;
+    } else {
+        src = (const uint8_t*)c->dPyr.p + L.off + (int64_t)frame * L.frameStride;
+        pitch = L.pitch;
+    }
+    HIP_TRY(hipMemcpy2D(dst, dst_stride, src, pitch, L.w, L.h, hipMemcpyDeviceToHost));
+    return ORB_OK;
+}
+
+extern "C" int orb_debug_get_fast_keys(orb_ctx* c, int frame, int level, int* xs, int* ys, int* scores, int cap,
+                                       int* n_out) {
+    if (!c || !c->geomValid || !n_out) {
+        orb_set_error("orb_debug_get_fast_keys: bad arguments");
+        return ORB_ERR_INVALID;
+    }
+    const OrbGeom& g = c->geom;
+    if (level < 0 || level >= g.nlevels || frame < 0 || frame >= c->lastFrames) {
+        orb_set_error("frame %d / level %d out of range", frame, level);
+        return ORB_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->prm.device));
+    HIP_TRY(hipDeviceSynchronize());
+    const OrbLevel& L = g.lv[level];
+    const int nCells = L.nCols * L.nRows;
+    std::vector<int> cnt(nCells);
+    std::vector<uint32_t> keys((size_t)nCells * g.cellCap);
+    const int64_t cell0 = (int64_t)frame * g.cellsPerFrame + L.cellBase;
+    HIP_TRY(hipMemcpy(cnt.data(), (int*)c->dCellCount.p + cell0, (size_t)nCells * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(keys.data(), (uint32_t*)c->dCellKeys.p + cell0 * g.cellCap, keys.size() * 4,
+                      hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int ci = 0; ci < nCells; ci++) {
+        const int i = ci / L.nCols, j = ci % L.nCols;
+        for (int k = 0; k < cnt[ci]; k++) {
+            const uint32_t key = keys[(size_t)ci * g.cellCap + k];
+            if (n < cap) {
+                if (xs) xs[n] = 3 + j * L.wCell + (int)(key & 0xff);
+                if (ys) ys[n] = 3 + i * L.hCell + (int)((key >> 8) & 0xff);
+                if (scores) scores[n] = (int)(key >> 16);
+            }
+            n++;
+        }
+    }
+    *n_out = n;
+    return ORB_OK;
+}
+
+extern "C" int orb_resize(orb_ctx* c, const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh,
+                          int dstride, int area) {
+    if (!c || !src || !dst || sw < 1 || sh < 1 || dw < 1 || dh < 1 || sstride < sw || dstride < dw) {
+        orb_set_error("orb_resize: bad arguments");
+        return ORB_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->prm.device));
+    std::vector<OrbAreaTap> at;
+    std::vector<OrbLinTap> lt;
+    int rc;
+    if (area) {
+        if ((rc = area_taps(sw, dw, at))) return rc;
+        if ((rc = area_taps(sh, dh, at))) return rc;
+    } else {
+        linear_taps(sw, dw, true, lt);
+        linear_taps(sh, dh, false, lt);
+    }
+    DevBuf dS, dD, dT;
+    const size_t tabBytes = area ? at.size() * sizeof(OrbAreaTap) : lt.size() * sizeof(OrbLinTap);
+    rc = dS.ensure((size_t)sstride * sh);
+    if (!rc) rc = dD.ensure((size_t)dstride * dh);
+    if (!rc) rc = dT.ensure(tabBytes);
+    if (!rc) {
+        hipError_t e = hipMemcpy(dS.p, src, (size_t)sstride * (sh - 1) + sw, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dT.p, area ? (void*)at.data() : (void*)lt.data(), tabBytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            rc = orb_launch_resize_single((const uint8_t*)dS.p, sw, sh, sstride, (uint8_t*)dD.p, dw, dh, dstride,
+                                          (const OrbAreaTap*)dT.p, (const OrbAreaTap*)dT.p + dw, (const OrbLinTap*)dT.p,
+                                          (const OrbLinTap*)dT.p + dw, area, nullptr);
+            if (!rc) e = hipDeviceSynchronize();
+            if (!rc && e == hipSuccess) e = hipMemcpy2D(dst, dstride, dD.p, dstride, dw, dh, hipMemcpyDeviceToHost);
+        }
+        if (e != hipSuccess) {
+            orb_set_error("orb_resize: %s", hipGetErrorString(e));
+            rc = ORB_ERR_HIP;
+        }
+    }
+    dS.release();
+    dD.release();
+    dT.release();
+    return rc;
+}
+
+extern "C" int orb_gaussian_blur(orb_ctx* c, const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride) {
+    if (!c || !src || !dst || w < 1 || h < 1 || sstride < w || dstride < w) {
+        orb_set_error("orb_gaussian_blur: bad arguments");
+        return ORB_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->prm.device));
+    DevBuf dS, dD;
+    int rc = dS.ensure((size_t)sstride * h);
+    if (!rc) rc = dD.ensure((size_t)dstride * h);
+    if (!rc) {
+        hipError_t e = hipMemcpy(dS.p, src, (size_t)sstride * (h - 1) + w, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            rc = orb_launch_blur_single((const uint8_t*)dS.p, w, h, sstride, (uint8_t*)dD.p, dstride,
+                                        (c->prm.quirks & ORB_Q_GAUSS_LEGACY) ? 1 : 0, nullptr);
+            if (!rc) e = hipDeviceSynchronize();
+            if (!rc && e == hipSuccess) e = hipMemcpy2D(dst, dstride, dD.p, dstride, w, h, hipMemcpyDeviceToHost);
+        }
+        if (e != hipSuccess) {
+            orb_set_error("orb_gaussian_blur: %s", hipGetErrorString(e));
+            rc = ORB_ERR_HIP;
+        }
+    }
+    dS.release();
+    dD.release();
+    return rc;
+}
+
+// ORBmatcher::DescriptorDistance, src/ORBmatcher.cc:460-476: population count of the 256-bit XOR.
+extern "C" int orb_hamming(const uint8_t a[32], const uint8_t b[32]) {
+    uint64_t x[4], y[4];
+    memcpy(x, a, 32);
+    memcpy(y, b, 32);
+    return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) + __builtin_popcountll(x[2] ^ y[2]) +
+           __builtin_popcountll(x[3] ^ y[3]);
+}

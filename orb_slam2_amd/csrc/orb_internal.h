@@ -1,0 +1,107 @@
+// Internal declarations shared by the host side of liborbhip and its kernels.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/orb_hip.h"
+
+#define ORB_MAX_LEVELS 12
+#define ORB_MAX_TAPS 4          // source cells one destination pixel of the area resize may cover per axis
+#define ORB_EDGE 19             // EDGE_THRESHOLD, src/ORBextractor.cc:21
+#define ORB_BORDER 16           // EDGE_THRESHOLD - 3, src/ORBextractor.cc:808
+#define ORB_CELL_MAX 64         // a FAST cell interior is at most 59 pixels wide / high
+#define ORB_CODE_DEPTH 14       // quadtree path digits kept per key (2 bits each) + 4 bits initial node
+#define ORB_GRID_COLS 64        // include/Frame.h:17
+#define ORB_GRID_ROWS 48        // include/Frame.h:16
+#define ORB_HISTO 30            // src/ORBmatcher.cc:18
+
+// Geometry of one pyramid level for the current frame size.
+struct OrbLevel {
+    int w, h, pitch;            // level image, row pitch in the pyramid buffer
+    int64_t off;                // byte offset of frame 0 inside the pyramid buffer (levels >= 1)
+    int64_t frameStride;        // bytes between consecutive frames of this level
+    int nCols, nRows, wCell, hCell;  // FAST cell grid, src/ORBextractor.cc:816-823
+    int maxBorderX, maxBorderY;
+    int cellBase;               // index of the level's first cell within a frame
+    int nIni;                   // quadtree initial nodes, src/ORBextractor.cc:574
+    float hX;                   // :576
+    int quota;                  // mnFeaturesPerLevel[level]
+    int outCap;                 // most keypoints the level can emit
+    int outBase;                // sum of outCap of the lower levels
+    int64_t keyBase;            // sum of keyCap of the lower levels
+    int keyCap;                 // most keys FAST can hand to the quadtree on this level
+    int nodeCap;                // node-pool entries per (frame, level)
+    int64_t nodeBase;           // sum of nodeCap of the lower levels
+    float scale;                // mvScaleFactor[level]
+    float patchSize;            // (float)(int)(31 * scale)
+    int tabX, tabY;             // first entry of the level's resize taps in the tap table
+};
+
+struct OrbGeom {
+    int nlevels, w, h;
+    int cellsPerFrame, cellCap;   // cellCap: key slots per cell
+    int outCapFrame;              // sum of outCap
+    int64_t keysPerFrame;         // sum of keyCap
+    int64_t nodesPerFrame;        // sum of nodeCap
+    int iniTh, minTh;
+    unsigned quirks;
+    unsigned long long umaxPacked;  // 16 x 4 bits
+    OrbLevel lv[ORB_MAX_LEVELS];
+};
+
+struct OrbAreaTap {  // one destination index of the area resize: up to 4 source cells and their weights
+    int si[ORB_MAX_TAPS];
+    float a[ORB_MAX_TAPS];
+};
+struct OrbLinTap {   // one destination index of the linear resize
+    int s0, s1, a0, a1;
+};
+
+// Quadtree node as the kernel keeps it (keys of a node are a contiguous range of the code-sorted key array).
+struct OrbNode {
+    int lo, hi;      // key range [lo, hi)
+    int depthFlags;  // depth | noMore << 8
+    int seq;         // creation number
+};
+
+// ---- kernel launchers (defined in the .hip files) --------------------------------
+struct OrbBatch {  // everything one extraction launch sequence needs
+    const OrbGeom* d_geom;
+    const OrbGeom* h_geom;
+    const uint8_t* d_img0;      // level 0 = the caller's frames
+    int stride0;
+    int64_t frameStride0;
+    int nframes;
+    uint8_t* d_pyr;             // levels >= 1, level-major
+    const OrbAreaTap* d_areaTaps;
+    const OrbLinTap* d_linTaps;
+    uint32_t* d_cellKeys;       // [frame][cell][cellCap]: x | y << 8 | score << 16, cell-interior coordinates
+    int* d_cellCount;           // [frame][cell]
+    int* d_cellOff;             // [frame][cellsPerFrame + nlevels] scan scratch
+    unsigned long long* d_sort; // [frame][keysPerFrame]: quadtree path << 32 | rank
+    unsigned long long* d_keyInfo;  // [frame][keysPerFrame]: x | y << 16 | score << 32 by rank
+    OrbNode* d_nodes;           // [frame][nodesPerFrame * 2]
+    int* d_ints;                // [frame][nodesPerFrame * 9 + nlevels * 4]
+    uint32_t* d_selXY;          // [frame][outCapFrame]: x | y << 16 (relative to the 16-pixel border)
+    int* d_selScore;            // [frame][outCapFrame]
+    int* d_levelCount;          // [frame][nlevels] keypoints kept per level
+    int* d_levelKeys;           // [frame][nlevels] keys handed to the quadtree
+    int* d_error;               // flag word, OR of limit bits
+    orb_keypoint* d_kps;
+    uint8_t* d_desc;
+    int capPerFrame;
+    int* d_nOut;
+    void* stream;
+};
+
+int orb_launch_pyramid(const OrbBatch& b);
+int orb_launch_fast(const OrbBatch& b);
+int orb_launch_quadtree(const OrbBatch& b);
+int orb_launch_describe(const OrbBatch& b);
+
+int orb_launch_resize_single(const uint8_t* d_src, int sw, int sh, int sstride, uint8_t* d_dst, int dw, int dh,
+                             int dstride, const OrbAreaTap* d_ax, const OrbAreaTap* d_ay, const OrbLinTap* d_lx,
+                             const OrbLinTap* d_ly, int area, void* stream);
+int orb_launch_blur_single(const uint8_t* d_src, int w, int h, int sstride, uint8_t* d_dst, int dstride, int legacy,
+                           void* stream);
+
+void orb_set_error(const char* fmt, ...);

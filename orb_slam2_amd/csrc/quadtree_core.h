@@ -1,0 +1,399 @@
+// Quadtree keypoint distribution for one (frame, level), written once for the
+// device (one workgroup, QT_NT threads, phases separated by workgroup
+// barriers) and for a single-threaded host build used by the unit tests
+// (ORB_HOST_EMU: one "thread", barriers are no-ops).
+//
+// Follows ORBextractor::DistributeOctTree / ExtractorNode::DivideNode of the
+// reference (src/ORBextractor.cc:511-796) with these observations:
+//  * a node's rectangle is fixed by its initial node and its path of quadrant
+//    choices, and a key's path depends only on its own coordinates; keys are
+//    therefore sorted once by (initial node, path) and every node owns a
+//    contiguous range of that order — dividing a node is three binary searches;
+//  * a coarse pass divides every divisible node, so the new list is
+//    [children of the last divisible node (n4..n1), ..., children of the first]
+//    followed by the untouched nodes in their old order — prefix sums;
+//  * the fine phase divides recorded nodes by decreasing (size, creation
+//    number) and stops at the first node that brings the list to the quota —
+//    a prefix sum over that order finds the stopping point;
+//  * the per-node winner is the largest response, earliest key on ties.
+#pragma once
+#include <stdint.h>
+
+#include "orb_internal.h"
+
+#ifdef ORB_HOST_EMU
+#define QT_FN static inline
+#define QT_BARRIER() ((void)0)
+#define QT_TID 0
+#define QT_NT 1
+#define QT_FDIV(a, b) ((a) / (b))
+#else
+#define QT_FN static __device__ __forceinline__
+#define QT_BARRIER() __syncthreads()
+#define QT_TID ((int)threadIdx.x)
+#define QT_NT ((int)blockDim.x)
+#define QT_FDIV(a, b) __fdiv_rn((a), (b))
+#endif
+
+#define QT_NOMORE 0x100
+#define QT_DEPTH(n) ((n).depthFlags & 0xff)
+
+struct QtShared {
+    int part[1024];  // per-thread partial sums of the block scan
+    int total;
+    int nL, prevSize, nToExpand, seqCounter, nRec, finish, fine, stop, err;
+};
+
+struct QtWork {  // scratch of one (frame, level), all in global memory
+    unsigned long long* sorted;  // n entries: code << 32 | rank, ascending
+    OrbNode* listA;              // nodeCap
+    OrbNode* listB;              // nodeCap
+    int* rec;                    // nodeCap: positions (in the current list) of recorded nodes
+    int* recSorted;              // nodeCap
+    int* bounds;                 // nodeCap * 4: child boundaries b1,b2,b3 and flags per node
+    int* scanA;                  // nodeCap + 1
+    int* scanB;                  // nodeCap + 1
+    int* scanC;                  // nodeCap + 1
+    int nodeCap;
+};
+
+// Quadtree path of a key: 4 bits initial node, then ORB_CODE_DEPTH two-bit
+// quadrant digits (0 = n1 left/top, 1 = n2 right/top, 2 = n3 left/bottom,
+// 3 = n4 right/bottom), src/ORBextractor.cc:516-559, 583-602.
+QT_FN uint32_t qt_code(int x, int y, int nIni, float hX, int height) {
+    int ini = (int)QT_FDIV((float)x, hX);
+    if (ini > nIni - 1) ini = nIni - 1;  // (never taken for in-range keys; keeps the index safe)
+    int x0 = (int)(hX * (float)ini), x1 = (int)(hX * (float)(ini + 1));
+    int y0 = 0, y1 = height;
+    uint32_t code = (uint32_t)ini;
+    for (int d = 0; d < ORB_CODE_DEPTH; d++) {
+        const int halfX = (x1 - x0 + 1) >> 1;  // ceil((UR.x-UL.x)/2)
+        const int halfY = (y1 - y0 + 1) >> 1;
+        const int mx = x0 + halfX, my = y0 + halfY;
+        const int right = !(x < mx), bottom = !(y < my);
+        code = (code << 2) | (uint32_t)(bottom * 2 + right);
+        if (right) x0 = mx; else x1 = mx;
+        if (bottom) y0 = my; else y1 = my;
+    }
+    return code;
+}
+
+// First index in [lo, hi) whose code is >= key (codes are the high 32 bits).
+QT_FN int qt_lower_bound(const unsigned long long* s, int lo, int hi, uint32_t key) {
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((uint32_t)(s[mid] >> 32) < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// Exclusive prefix sum of a[0..n) in place; a[n] and sh->total receive the sum.
+QT_FN void qt_scan(int* a, int n, QtShared* sh) {
+    const int T = QT_NT, t = QT_TID;
+    const int chunk = (n + T - 1) / T;
+    const int b = t * chunk, e = (b + chunk < n) ? b + chunk : n;
+    int s = 0;
+    for (int i = b; i < e; i++) s += a[i];
+    sh->part[t] = s;
+    QT_BARRIER();
+    if (t == 0) {
+        int run = 0;
+        for (int i = 0; i < T; i++) {
+            const int v = sh->part[i];
+            sh->part[i] = run;
+            run += v;
+        }
+        sh->total = run;
+        a[n] = run;
+    }
+    QT_BARRIER();
+    int run = sh->part[t];
+    for (int i = b; i < e; i++) {
+        const int v = a[i];
+        a[i] = run;
+        run += v;
+    }
+    QT_BARRIER();
+}
+
+// Child boundaries of a node: b[0..2] = first key of n2, n3, n4 inside [lo,hi).
+// Returns 0 and sets *err when the node is deeper than the stored path.
+QT_FN void qt_children(const unsigned long long* s, const OrbNode& nd, int* b, int* err) {
+    const int d = QT_DEPTH(nd);
+    if (d >= ORB_CODE_DEPTH) {  // cannot happen for frames within the size limit; fail loudly
+        *err = 1;
+        b[0] = b[1] = b[2] = nd.hi;
+        return;
+    }
+    const int shift = 2 * (ORB_CODE_DEPTH - 1 - d);
+    const uint32_t prefix = (uint32_t)(s[nd.lo] >> 32) >> shift >> 2 << 2;  // parent's digits, child digit cleared
+    if (nd.hi - nd.lo == 1) {
+        const int q = (int)(((uint32_t)(s[nd.lo] >> 32) >> shift) & 3);
+        b[0] = q >= 1 ? nd.lo : nd.hi;
+        b[1] = q >= 2 ? nd.lo : nd.hi;
+        b[2] = q >= 3 ? nd.lo : nd.hi;
+        return;
+    }
+    b[0] = qt_lower_bound(s, nd.lo, nd.hi, (prefix | 1u) << shift);
+    b[1] = qt_lower_bound(s, b[0], nd.hi, (prefix | 2u) << shift);
+    b[2] = qt_lower_bound(s, b[1], nd.hi, (prefix | 3u) << shift);
+}
+
+QT_FN int qt_child_flags(int q, int cnt, int n3quirk) {
+    // src/ORBextractor.cc:561-568: one-key children stop; with the fork's stray
+    // ';' n3 always stops and n4 never does.
+    if (n3quirk) {
+        if (q == 2) return QT_NOMORE;
+        if (q == 3) return 0;
+    }
+    return cnt == 1 ? QT_NOMORE : 0;
+}
+
+// Writes the children of `nd` (boundaries b) in list order n4,n3,n2,n1 starting
+// at dst[pos]; creation numbers run n1..n4 from seq0.  Children with more than
+// one key are recorded at rec[recPos..].
+QT_FN void qt_emit_children(const OrbNode& nd, const int* b, OrbNode* dst, int pos, int seq0, int* rec, int recPos,
+                            int n3quirk) {
+    const int lo[4] = {nd.lo, b[0], b[1], b[2]};
+    const int hi[4] = {b[0], b[1], b[2], nd.hi};
+    int seqs[4], s = seq0;
+    for (int q = 0; q < 4; q++) seqs[q] = (hi[q] > lo[q]) ? s++ : -1;
+    const int d = QT_DEPTH(nd) + 1;
+    for (int q = 3; q >= 0; q--) {
+        const int cnt = hi[q] - lo[q];
+        if (cnt <= 0) continue;
+        OrbNode c;
+        c.lo = lo[q];
+        c.hi = hi[q];
+        c.depthFlags = d | qt_child_flags(q, cnt, n3quirk);
+        c.seq = seqs[q];
+        dst[pos] = c;
+        pos++;
+    }
+    // record in creation order (n1..n4); the position of child q in dst is pos_end - 1 - (index among non-empty)
+    int idx = 0, nonEmpty = 0;
+    for (int q = 0; q < 4; q++) nonEmpty += (hi[q] > lo[q]);
+    const int base = pos - nonEmpty;
+    for (int q = 0; q < 4; q++) {
+        const int cnt = hi[q] - lo[q];
+        if (cnt <= 0) continue;
+        if (cnt > 1) rec[recPos++] = base + (nonEmpty - 1 - idx);
+        idx++;
+    }
+}
+
+// Runs the distribution.  `sorted` holds n (code, rank) entries in ascending
+// order.  On return *outCount nodes are in `*outList` in list order.
+QT_FN void qt_distribute(const QtWork& w, int n, int nIni, int N, int n3quirk, QtShared* sh, OrbNode** outList,
+                         int* outCount) {
+    const int T = QT_NT, t = QT_TID;
+    const unsigned long long* s = w.sorted;
+    OrbNode* cur = w.listA;
+    OrbNode* nxt = w.listB;
+
+    // ---- initial nodes, src/ORBextractor.cc:583-616 -------------------------------
+    if (t == 0) {
+        int nL = 0;
+        for (int i = 0; i < nIni; i++) {
+            const int lo = qt_lower_bound(s, 0, n, (uint32_t)i << (2 * ORB_CODE_DEPTH));
+            const int hi = (i + 1 == nIni) ? n : qt_lower_bound(s, lo, n, (uint32_t)(i + 1) << (2 * ORB_CODE_DEPTH));
+            if (hi == lo) continue;
+            OrbNode nd;
+            nd.lo = lo;
+            nd.hi = hi;
+            nd.depthFlags = (hi - lo == 1) ? QT_NOMORE : 0;
+            nd.seq = i;
+            cur[nL++] = nd;
+        }
+        sh->nL = nL;
+        sh->seqCounter = nIni;
+        sh->finish = 0;
+        sh->err = 0;
+    }
+    QT_BARRIER();
+
+    while (!sh->finish) {
+        // ---- coarse pass, src/ORBextractor.cc:625-697 ------------------------------
+        const int nL = sh->nL;
+        for (int i = t; i < nL; i += T) {
+            const OrbNode nd = cur[i];
+            int k = 0, e = 0, nm = 1;
+            if (!(nd.depthFlags & QT_NOMORE)) {
+                int b[3];
+                int err = 0;
+                qt_children(s, nd, b, &err);
+                if (err) sh->err = 1;
+                w.bounds[4 * i + 0] = b[0];
+                w.bounds[4 * i + 1] = b[1];
+                w.bounds[4 * i + 2] = b[2];
+                const int c0 = b[0] - nd.lo, c1 = b[1] - b[0], c2 = b[2] - b[1], c3 = nd.hi - b[2];
+                k = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+                e = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
+                nm = 0;
+            }
+            w.scanA[i] = k;
+            w.scanB[i] = e;
+            w.scanC[i] = nm;
+        }
+        QT_BARRIER();
+        qt_scan(w.scanA, nL, sh);
+        qt_scan(w.scanB, nL, sh);
+        qt_scan(w.scanC, nL, sh);
+        const int totalChildren = w.scanA[nL], nToExpand = w.scanB[nL], nStay = w.scanC[nL];
+        if (totalChildren + nStay > w.nodeCap) {  // cannot happen by the size bound; fail loudly
+            if (t == 0) { sh->err = 2; sh->finish = 1; }
+            QT_BARRIER();
+            break;
+        }
+        const int seq0 = sh->seqCounter;
+        for (int i = t; i < nL; i += T) {
+            const OrbNode nd = cur[i];
+            if (nd.depthFlags & QT_NOMORE) {
+                nxt[totalChildren + w.scanC[i]] = nd;
+            } else {
+                const int k = w.scanA[i + 1] - w.scanA[i];
+                const int pos = totalChildren - w.scanA[i] - k;  // blocks of later nodes come first
+                qt_emit_children(nd, &w.bounds[4 * i], nxt, pos, seq0 + w.scanA[i], w.rec, w.scanB[i], n3quirk);
+            }
+        }
+        QT_BARRIER();
+        if (t == 0) {
+            const int newL = totalChildren + nStay;
+            sh->prevSize = nL;
+            sh->nL = newL;
+            sh->nRec = nToExpand;
+            sh->seqCounter = seq0 + totalChildren;
+            sh->fine = 0;
+            if (newL >= N || newL == nL) sh->finish = 1;
+            else if (newL + nToExpand * 3 > N) sh->fine = 1;
+        }
+        { OrbNode* tmp = cur; cur = nxt; nxt = tmp; }
+        QT_BARRIER();
+
+        // ---- fine phase, src/ORBextractor.cc:702-770 ------------------------------
+        while (sh->fine && !sh->finish) {
+            const int nLf = sh->nL, nR = sh->nRec;
+            // order recorded nodes by (size, creation number) descending
+            for (int j = t; j < nR; j += T) {
+                const OrbNode a = cur[w.rec[j]];
+                const int sa = a.hi - a.lo;
+                int r = 0;
+                for (int m = 0; m < nR; m++) {
+                    const OrbNode c = cur[w.rec[m]];
+                    const int sc = c.hi - c.lo;
+                    r += (sc > sa) || (sc == sa && c.seq > a.seq);
+                }
+                w.recSorted[r] = w.rec[j];
+            }
+            QT_BARRIER();
+            for (int j = t; j < nR; j += T) {
+                const OrbNode nd = cur[w.recSorted[j]];
+                int b[3];
+                int err = 0;
+                qt_children(s, nd, b, &err);
+                if (err) sh->err = 1;
+                w.bounds[4 * j + 0] = b[0];
+                w.bounds[4 * j + 1] = b[1];
+                w.bounds[4 * j + 2] = b[2];
+                const int c0 = b[0] - nd.lo, c1 = b[1] - b[0], c2 = b[2] - b[1], c3 = nd.hi - b[2];
+                w.scanA[j] = (c0 > 0) + (c1 > 0) + (c2 > 0) + (c3 > 0);
+                w.scanB[j] = (c0 > 1) + (c1 > 1) + (c2 > 1) + (c3 > 1);
+            }
+            if (t == 0) sh->stop = nR - 1;
+            QT_BARRIER();
+            qt_scan(w.scanA, nR, sh);
+            qt_scan(w.scanB, nR, sh);
+            // the list reaches the quota after processing node j when nLf + (children - parents) >= N
+            for (int j = t; j < nR; j += T) {
+                const int after = nLf + w.scanA[j + 1] - (j + 1);
+                const int before = nLf + w.scanA[j] - j;
+                if (after >= N && before < N) sh->stop = j;  // unique: the running size never decreases
+            }
+            QT_BARRIER();
+            const int nProc = (nR > 0) ? sh->stop + 1 : 0;
+            const int childrenProc = w.scanA[nProc];
+            // survivors of the old list keep their order behind the new children
+            for (int i = t; i < nLf; i += T) w.scanC[i] = 1;
+            QT_BARRIER();
+            for (int j = t; j < nProc; j += T) w.scanC[w.recSorted[j]] = 0;
+            QT_BARRIER();
+            qt_scan(w.scanC, nLf, sh);
+            const int nSurv = w.scanC[nLf];
+            if (childrenProc + nSurv > w.nodeCap) {
+                if (t == 0) { sh->err = 2; sh->finish = 1; }
+                QT_BARRIER();
+                break;
+            }
+            const int seqF = sh->seqCounter;
+            for (int i = t; i < nLf; i += T)
+                if (w.scanC[i + 1] - w.scanC[i]) nxt[childrenProc + w.scanC[i]] = cur[i];
+            for (int j = t; j < nProc; j += T) {
+                const OrbNode nd = cur[w.recSorted[j]];
+                const int k = w.scanA[j + 1] - w.scanA[j];
+                const int pos = childrenProc - w.scanA[j] - k;
+                qt_emit_children(nd, &w.bounds[4 * j], nxt, pos, seqF + w.scanA[j], w.rec, w.scanB[j], n3quirk);
+            }
+            QT_BARRIER();
+            if (t == 0) {
+                const int newL = childrenProc + nSurv;
+                sh->nRec = w.scanB[nProc];
+                sh->seqCounter = seqF + childrenProc;
+                sh->nL = newL;
+                if (newL >= N || newL == nLf) sh->finish = 1;
+            }
+            { OrbNode* tmp = cur; cur = nxt; nxt = tmp; }
+            QT_BARRIER();
+        }
+    }
+    *outList = cur;
+    *outCount = sh->nL;
+}
+
+// In-place ascending sort of a[0..n) by the whole 64-bit value: bitonic network
+// in its all-ascending form (first step of every merge mirrors the upper half),
+// so indices >= n act as +infinity without being stored.
+QT_FN void qt_sort(unsigned long long* a, int n) {
+    const int T = QT_NT, t = QT_TID;
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    const int pairs = np2 >> 1;
+    for (int k = 2; k <= np2; k <<= 1) {
+        const int hk = k >> 1;
+        for (int p = t; p < pairs; p += T) {
+            const int blk = p / hk, o = p - blk * hk;
+            const int i = blk * k + o, j = blk * k + k - 1 - o;
+            if (j < n) {
+                const unsigned long long x = a[i], y = a[j];
+                if (x > y) { a[i] = y; a[j] = x; }
+            }
+        }
+        QT_BARRIER();
+        for (int jj = k >> 2; jj > 0; jj >>= 1) {
+            for (int p = t; p < pairs; p += T) {
+                const int blk = p / jj, o = p - blk * jj;
+                const int i = blk * 2 * jj + o, j = i + jj;
+                if (j < n) {
+                    const unsigned long long x = a[i], y = a[j];
+                    if (x > y) { a[i] = y; a[j] = x; }
+                }
+            }
+            QT_BARRIER();
+        }
+    }
+}
+
+// Winner of a node: largest response, earliest key (smallest rank) on ties
+// (src/ORBextractor.cc:777-793).  info[rank] = x | y << 16 | score << 32.
+QT_FN int qt_select(const unsigned long long* sorted, const unsigned long long* info, const OrbNode& nd) {
+    int bestRank = (int)(uint32_t)sorted[nd.lo];
+    int bestScore = (int)(info[bestRank] >> 32);
+    for (int i = nd.lo + 1; i < nd.hi; i++) {
+        const int r = (int)(uint32_t)sorted[i];
+        const int sc = (int)(info[r] >> 32);
+        if (sc > bestScore || (sc == bestScore && r < bestRank)) {
+            bestScore = sc;
+            bestRank = r;
+        }
+    }
+    return bestRank;
+}

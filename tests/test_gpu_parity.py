@@ -1,0 +1,299 @@
+"""GPU parity: the HIP path (through the C ABI, include/orb_hip.h) against the
+CPU oracle on the same seeded inputs.  Integer, byte and index results must be
+bit-exact; the orientation angle is also compared bit-exactly (the north-star
+tolerance for it is 1e-4 degrees, asserted as well so a regression reports
+which of the two bars it crossed).
+"""
+import numpy as np
+import pytest
+
+from orb_slam2_amd.synth import frame_seed, splitmix64, synth_descriptors, synth_queries, synth_scene
+
+pytestmark = pytest.mark.gpu
+
+PRESETS = {"fork": 0x1F, "canonical": 0}
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from orb_slam2_amd import binding
+
+    binding.lib()  # fails loudly if the HIP library is missing
+    return binding
+
+
+def _ctx(hip, preset, nfeatures=1000, nlevels=8, w=640, h=480, batch=1):
+    return hip.Context(nfeatures, 1.2, nlevels, 20, 7, w, h, batch, 0, PRESETS[preset])
+
+
+def assert_kps_equal(got, ref, what=""):
+    assert len(got) == len(ref), "%s: %d keypoints, oracle %d" % (what, len(got), len(ref))
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        np.testing.assert_array_equal(got[f], ref[f], err_msg="%s field %s" % (what, f))
+    d = np.abs(got["angle"].astype(np.float64) - ref["angle"].astype(np.float64))
+    d = np.minimum(d, 360 - d)
+    assert (d <= 1e-4).all(), "%s: angle differs by up to %g degrees" % (what, d.max())
+    np.testing.assert_array_equal(got["angle"], ref["angle"], err_msg="%s angle not bit-exact" % what)
+
+
+@pytest.mark.parametrize("preset", ["fork", "canonical"])
+def test_tables(hip, oracle, preset):
+    for nf in (1000, 2000, 4000):
+        c = _ctx(hip, preset, nf)
+        e = oracle.Extractor(nf, 1.2, 8, 20, 7, PRESETS[preset])
+        tg, to = c.tables(), e.tables()
+        for k in tg:
+            np.testing.assert_array_equal(tg[k], to[k], err_msg=k)
+        c.close()
+
+
+@pytest.mark.parametrize("area", [True, False])
+def test_resize(hip, oracle, area):
+    c = _ctx(hip, "fork")
+    for (w, h, dw, dh, seed) in [(640, 480, 533, 400, 1), (533, 400, 444, 333, 2), (179, 134, 149, 112, 3),
+                                 (1241, 376, 1034, 313, 4), (97, 61, 80, 50, 5), (64, 64, 40, 33, 6)]:
+        img = synth_scene(w, h, seed)
+        np.testing.assert_array_equal(c.resize(img, dw, dh, area), oracle.resize(img, dw, dh, area),
+                                      err_msg="%dx%d->%dx%d area=%s" % (w, h, dw, dh, area))
+    # strided input
+    big = synth_scene(700, 300, 9)
+    view = big[10:250, 20:620]
+    np.testing.assert_array_equal(c.resize(np.ascontiguousarray(view), 500, 200, area), oracle.resize(view, 500, 200, area))
+    c.close()
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+def test_gaussian_blur(hip, oracle, legacy):
+    c = hip.Context(1000, 1.2, 8, 20, 7, 640, 480, 1, 0, 0x1F | (hip.ORB_Q_GAUSS_LEGACY if legacy else 0))
+    for (w, h, seed) in [(640, 480, 1), (179, 134, 2), (65, 17, 3), (7, 7, 4), (5, 3, 5), (1, 9, 6), (130, 1, 7)]:
+        img = synth_scene(w, h, seed)
+        np.testing.assert_array_equal(c.gaussian_blur(img), oracle.gaussian(img, legacy), err_msg="%dx%d" % (w, h))
+    sat = np.full((40, 40), 255, np.uint8)
+    np.testing.assert_array_equal(c.gaussian_blur(sat), oracle.gaussian(sat, legacy))
+    c.close()
+
+
+CASES = [  # (w, h, nfeatures, nlevels, config id)
+    (640, 480, 1000, 8, 1),
+    (1241, 376, 2000, 8, 2),
+    (752, 480, 2000, 8, 3),
+    (160, 120, 300, 4, 1),
+    (333, 517, 500, 6, 1),
+]
+
+
+@pytest.mark.parametrize("preset", ["fork", "canonical"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%d" % (c[0], c[1]))
+def test_extract_stages_and_end_to_end(hip, oracle, preset, case):
+    w, h, nf, nl, cfg = case
+    c = _ctx(hip, preset, nf, nl, w, h)
+    e = oracle.Extractor(nf, 1.2, nl, 20, 7, PRESETS[preset])
+    for f in range(2):
+        img = synth_scene(w, h, frame_seed(cfg, f))
+        kg, dg = c.extract(img)
+        ko, do = e.extract(img)
+        for l in range(nl):
+            np.testing.assert_array_equal(c.pyramid_level(0, l), e.level(l), err_msg="pyramid level %d" % l)
+        for l in range(nl):
+            xs, ys, sc = c.fast_keys(0, l)
+            ref = e.level_keys(l, after_quadtree=False)
+            assert len(xs) == len(ref), "level %d: %d FAST keys, oracle %d" % (l, len(xs), len(ref))
+            np.testing.assert_array_equal(xs, ref["x"].astype(np.int32), err_msg="FAST x level %d" % l)
+            np.testing.assert_array_equal(ys, ref["y"].astype(np.int32), err_msg="FAST y level %d" % l)
+            np.testing.assert_array_equal(sc, ref["response"].astype(np.int32), err_msg="FAST score level %d" % l)
+        assert_kps_equal(kg, ko, "frame %d" % f)
+        np.testing.assert_array_equal(dg, do, err_msg="descriptors frame %d" % f)
+    c.close()
+
+
+def test_extract_batch_equals_single(hip, oracle):
+    n = 5
+    c = _ctx(hip, "fork", batch=n)
+    e = oracle.Extractor(1000, 1.2, 8, 20, 7, PRESETS["fork"])
+    imgs = [synth_scene(640, 480, frame_seed(1, 10 + f)) for f in range(n)]
+    res = c.extract_batch(imgs)
+    for f in range(n):
+        ko, do = e.extract(imgs[f])
+        assert_kps_equal(res[f][0], ko, "batch frame %d" % f)
+        np.testing.assert_array_equal(res[f][1], do)
+        np.testing.assert_array_equal(c.pyramid_level(f, 3), e.level(3))
+    # a smaller batch and a smaller frame on the same context
+    res2 = c.extract_batch(imgs[:2])
+    for f in range(2):
+        np.testing.assert_array_equal(res2[f][1], res[f][1])
+    small = synth_scene(320, 240, 77)
+    ks, ds = c.extract(small)
+    ko, do = e.extract(small)
+    assert_kps_equal(ks, ko, "small frame on a large context")
+    np.testing.assert_array_equal(ds, do)
+    c.close()
+
+
+def test_extract_device_entry_point(hip, oracle):
+    import torch
+
+    n, w, h = 3, 640, 480
+    c = _ctx(hip, "fork", batch=n)
+    e = oracle.Extractor(1000, 1.2, 8, 20, 7, PRESETS["fork"])
+    imgs = np.stack([synth_scene(w, h, frame_seed(1, 20 + f)) for f in range(n)])
+    # padded rows: stride 704
+    buf = torch.zeros((n, h, 704), dtype=torch.uint8, device="cuda")
+    buf[:, :, :w] = torch.from_numpy(imgs).cuda()
+    d_imgs = buf[:, :, :w]
+    cap = c.cap
+    d_kps = torch.zeros((n, cap, 28), dtype=torch.uint8, device="cuda")
+    d_desc = torch.zeros((n, cap, 32), dtype=torch.uint8, device="cuda")
+    d_cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+    c.extract_batch_device(d_imgs, d_kps, d_desc, d_cnt)
+    torch.cuda.synchronize()
+    c.check_last_batch()
+    cnt = d_cnt.cpu().numpy()
+    for f in range(n):
+        ko, do = e.extract(imgs[f])
+        kg = d_kps[f, : cnt[f]].cpu().numpy().view(hip.KP_DTYPE).reshape(-1)
+        assert_kps_equal(kg, ko, "device frame %d" % f)
+        np.testing.assert_array_equal(d_desc[f, : cnt[f]].cpu().numpy(), do)
+    c.close()
+
+
+def test_empty_and_invalid_inputs(hip):
+    c = _ctx(hip, "fork")
+    k, d = c.extract(np.zeros((0, 0), np.uint8))
+    assert len(k) == 0 and len(d) == 0
+    flat = np.full((480, 640), 90, np.uint8)  # no corners at all
+    k, d = c.extract(flat)
+    assert len(k) == 0
+    with pytest.raises(hip.OrbError):  # coarsest level smaller than one FAST cell
+        c.extract(np.zeros((100, 100), np.uint8))
+    with pytest.raises(hip.OrbError):  # larger than the context was sized for
+        c.extract(np.zeros((481, 640), np.uint8))
+    with pytest.raises(hip.OrbError):
+        hip.Context(1000, 1.2, 8, 20, 0)  # minThFAST 0 is not covered by the single-score-map argument
+    c.close()
+
+
+def _pair(oracle, w, h, nf, seed, preset):
+    e = oracle.Extractor(nf, 1.2, 8, 20, 7, PRESETS[preset])
+    a = synth_scene(w, h, seed)
+    b = synth_scene(w, h, seed, shift=(3, 2), noise_seed=seed + 1)
+    k1, d1 = e.extract(a)
+    k2, d2 = e.extract(b)
+    return k1, d1, k2, d2
+
+
+@pytest.mark.parametrize("preset", ["fork", "canonical"])
+def test_search_for_initialization(hip, oracle, preset):
+    w, h = 752, 480
+    c = _ctx(hip, preset, 2000, 8, w, h)
+    for s in range(3):
+        k1, d1, k2, d2 = _pair(oracle, w, h, 2000, frame_seed(3, s), preset)
+        prev = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32)  # Tracking.cc:302-304
+        for (window, ratio, ori) in [(100, 0.9, True), (30, 0.9, True), (100, 0.6, False), (400, 0.95, True)]:
+            ng, mg, pg = c.match_window(k1, d1, k2, d2, w, h, prev, window, ratio, ori)
+            no, mo, po = oracle.search_for_initialization(k1, d1, k2, d2, w, h, prev, window, ratio, ori, PRESETS[preset])
+            np.testing.assert_array_equal(mg, mo, err_msg="matches12 window=%d" % window)
+            assert ng == no
+            np.testing.assert_array_equal(pg, po)
+        assert no > 50  # the pair really matches
+    # edge cases: empty frames, query positions far outside the image
+    empty_k = np.zeros(0, hip.KP_DTYPE)
+    empty_d = np.zeros((0, 32), np.uint8)
+    n, m, _ = c.match_window(k1, d1, empty_k, empty_d, w, h, prev)
+    assert n == 0 and (m == -1).all()
+    far = prev + 5000
+    ng, mg, _ = c.match_window(k1, d1, k2, d2, w, h, far)
+    no, mo, _ = oracle.search_for_initialization(k1, d1, k2, d2, w, h, far, 100, 0.9, True, PRESETS[preset])
+    assert ng == no == 0
+    c.close()
+
+
+@pytest.mark.parametrize("preset", ["fork", "canonical"])
+def test_search_by_projection(hip, oracle, preset):
+    w, h = 640, 480
+    c = _ctx(hip, preset, 1000, 8, w, h)
+    k1, d1, k2, d2 = _pair(oracle, w, h, 1000, frame_seed(1, 50), preset)
+    nq = len(k1)
+    r = splitmix64(4242, nq * 3)
+    jitter = ((r[: 2 * nq] % np.uint64(9)).astype(np.float32) - 4).reshape(nq, 2)
+    u = k1["x"] + 3 + jitter[:, 0]
+    v = k1["y"] + 2 + jitter[:, 1]
+    u[::37] = -5.0  # projections outside the image are skipped
+    scale = oracle.Extractor(1000, 1.2, 8, 20, 7, PRESETS[preset]).tables()["scale"]
+    for th in (15, 7, 30):
+        radius = th * scale[k1["octave"]]
+        lmin = k1["octave"] - 1
+        lmax = k1["octave"] + 1
+        qobs = (r[2 * nq :] % np.uint64(5) != 0).astype(np.uint8)
+        occ = (splitmix64(7, len(k2)) % np.uint64(11) == 0).astype(np.uint8)
+        for ori in (True, False):
+            ng, mg = c.match_projected(u, v, radius, lmin, lmax, k1["angle"], d1, qobs, k2, d2, w, h, occ, 100, ori)
+            no, mo = oracle.search_by_projection(u, v, radius, lmin, lmax, k1["angle"], d1, qobs, k2, d2, w, h, occ, 100, ori, PRESETS[preset])
+            np.testing.assert_array_equal(mg, mo, err_msg="th=%d ori=%s" % (th, ori))
+            assert ng == no
+    assert no > 50
+    c.close()
+
+
+def test_hamming_host(hip, oracle):
+    d = synth_descriptors(200, 5)
+    for i in range(199):
+        assert hip.hamming(d[i], d[i + 1]) == oracle.hamming(d[i], d[i + 1], bithack=True)
+
+
+def test_brute_force_top2(hip, oracle):
+    db = synth_descriptors(20011, 11)
+    q = synth_queries(db, 1500, 12)
+    # exact duplicates of a query's best row further down the database (ties for best)
+    db[15000:15040] = db[(splitmix64(5, 40) % np.uint64(5000)).astype(np.int64)]
+    q[200:240] = db[15000:15040]
+    bf = hip.BruteForce(0)
+    bf.set_database(db)
+    ig, bg, sg = bf.query_top2(q)
+    io, bo, so = oracle.bf_top2(q, db)
+    np.testing.assert_array_equal(ig, io)
+    np.testing.assert_array_equal(bg, bo)
+    np.testing.assert_array_equal(sg, so)
+    assert (bg[200:240] == 0).all() and (sg[200:240] == 0).all()
+    # ragged sizes: fewer rows than one group, one row, empty
+    for nd in (0, 1, 2, 3, 5, 257):
+        bf.set_database(db[:nd])
+        ig, bg, sg = bf.query_top2(q[:70])
+        io, bo, so = oracle.bf_top2(q[:70], db[:nd])
+        np.testing.assert_array_equal(ig, io)
+        np.testing.assert_array_equal(bg, bo)
+        np.testing.assert_array_equal(sg, so)
+    bf.close()
+
+
+def test_brute_force_sharded_merge(hip, oracle):
+    """Row shards on one device, packed per-shard results merged by the merge
+    kernel: equals the scan of the whole database (the all-gather only moves
+    the packed words)."""
+    import torch
+
+    db = synth_descriptors(30000, 21)
+    q = synth_queries(db, 999, 22)
+    db[29000:29030] = db[100:130]  # duplicates across shards
+    q[:30] = db[100:130]
+    io, bo, so = oracle.bf_top2(q, db)
+    d_q = torch.from_numpy(q).cuda()
+    for R in (1, 2, 3, 8):
+        bounds = [r * len(db) // R for r in range(R + 1)]
+        gathered = torch.zeros((R, len(q)), dtype=torch.int64, device="cuda")
+        shards = []
+        for r in range(R):
+            bf = hip.BruteForce(0)
+            d_db = torch.from_numpy(db[bounds[r] : bounds[r + 1]]).cuda()
+            bf.set_database_device(d_db, bounds[r])
+            bf.query_packed_device(d_q, gathered[r])
+            shards.append(bf)
+        d_idx = torch.zeros(len(q), dtype=torch.int32, device="cuda")
+        d_b = torch.zeros(len(q), dtype=torch.int16, device="cuda")
+        d_s = torch.zeros(len(q), dtype=torch.int16, device="cuda")
+        hip.merge_packed_device(0, gathered, R, len(q), d_idx, d_b, d_s)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(d_idx.cpu().numpy(), io, err_msg="R=%d" % R)
+        np.testing.assert_array_equal(d_b.cpu().numpy().view(np.uint16), bo)
+        np.testing.assert_array_equal(d_s.cpu().numpy().view(np.uint16), so)
+        for bf in shards:
+            bf.close()
