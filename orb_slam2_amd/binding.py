@@ -55,6 +55,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s is missing: build it with `make -C orb_slam2_amd/csrc` (hipcc, gfx950)" % LIB_PATH)
+        # PyTorch-ROCm bundles its own HIP/HSA runtime under the same soname.  Load it first so that
+        # this process holds ONE runtime: device pointers and streams of torch tensors are then valid
+        # inside liborbhip, and a second runtime never fights the first for the device.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.orb_last_error.restype = C.c_char_p
         L.orb_version.restype = C.c_char_p
