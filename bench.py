@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Benchmark of the ORB front end on MI355X.
+
+One process per GPU (launched by torch.distributed.run for --gpus > 1).  A
+"step" is one pass of ORBextractor::operator() over a batch of synthetic
+640x480 frames that already sit in HBM (1000 features, 8 levels, scale 1.2 —
+the configuration the headline metric is quoted on).  Frames are independent,
+so ranks share nothing on the data path (weak scaling: every rank extracts its
+own batch).  The same JSON line also carries the brute-force Hamming workload
+(100k queries x 10M database rows, rows sharded over the ranks, packed top-2
+all-gathered over RCCL and merged), the roofline of the dominant extraction
+kernel from HIP-event stage timings, and the CPU oracle timed on a bounded
+sample of the same frames.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, spec
+VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz: full-rate 32-bit integer lane-ops/s
+
+
+def level_geometry(w, h, nlevels, scale):
+    """Level sizes as src/ORBextractor.cc:917-918 computes them (float32 arithmetic)."""
+    s = np.float32(1.0)
+    out = []
+    for l in range(nlevels):
+        if l:
+            s = np.float32(np.float64(s) * np.float64(np.float32(scale)))
+        inv = np.float32(1.0) / s
+        out.append((int(np.rint(np.float32(w) * inv)), int(np.rint(np.float32(h) * inv))))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="frames per step and GPU")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--nfeatures", type=int, default=1000)
+    ap.add_argument("--preset", default="fork", choices=["fork", "canonical"])
+    ap.add_argument("--bf-queries", type=int, default=100000)
+    ap.add_argument("--bf-rows", type=int, default=10000000, help="database rows over ALL ranks")
+    ap.add_argument("--bf-steps", type=int, default=3)
+    ap.add_argument("--no-hamming", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=100)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from orb_slam2_amd import binding
+    from orb_slam2_amd.synth import frame_seed, splitmix64, synth_scene
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node N" % (world, args.gpus), file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    quirks = binding.ORB_QUIRKS_FORK if args.preset == "fork" else binding.ORB_QUIRKS_CANONICAL
+    W, H, B = args.width, args.height, args.batch
+
+    # ---- extraction ---------------------------------------------------------------------
+    frames = np.stack([synth_scene(W, H, frame_seed(1, rank * B + f)) for f in range(B)])
+    d_imgs = torch.from_numpy(frames).to(dev)
+    ctx = binding.Context(args.nfeatures, 1.2, 8, 20, 7, W, H, B, local, quirks)
+    cap = ctx.cap
+    d_kps = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        ctx.extract_batch_device(d_imgs, d_kps, d_desc, d_cnt, stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ctx.check_last_batch()
+    ctx.enable_stage_timing(True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    stage_ms, nrec = ctx.stage_timings()
+    ctx.enable_stage_timing(False)
+    ctx.check_last_batch()
+    counts = d_cnt.cpu().numpy()
+    fps = world * B * args.steps / dt
+
+    # algorithmic bytes per frame and stage (u8 pixels; P_l = pixels of level l, n = keypoints)
+    lv = level_geometry(W, H, 8, 1.2)
+    P = [w * h for (w, h) in lv]
+    nkp = float(counts.mean())
+    stage_bytes = {
+        "pyramid": sum(P[l - 1] + P[l] for l in range(1, 8)),      # read level l-1, write level l
+        "fast": sum(P),                                             # every level read once
+        "quadtree": 0,                                              # bookkeeping on keys, no pixel traffic
+        "describe": nkp * (43 * 43 + 28 + 32),                      # source window + keypoint + descriptor
+    }
+    dom = max(stage_ms, key=lambda k: stage_ms[k])
+    kernel_name = {"pyramid": "k_resize_area x7", "fast": "k_fast_cells", "quadtree": "k_quadtree", "describe": "k_describe"}[dom]
+    achieved = stage_bytes[dom] * B / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+        "algorithmic_bytes_per_launch": int(stage_bytes[dom] * B), "launch_ms": round(stage_ms[dom], 4),
+        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}, "stage_batches": nrec,
+    }
+
+    # ---- brute-force Hamming ------------------------------------------------------------
+    hamming = None
+    if not args.no_hamming:
+        nq, nd = args.bf_queries, args.bf_rows
+        lo, hi = rank * nd // world, (rank + 1) * nd // world
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + rank)
+        d_db = torch.randint(0, 256, (hi - lo, 32), dtype=torch.uint8, device=dev, generator=g)
+        gq = torch.Generator(device=dev)
+        gq.manual_seed(99)
+        d_q = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device=dev, generator=gq)
+        bf = binding.BruteForce(local)
+        bf.set_database_device(d_db, lo)
+        d_packed = torch.zeros(nq, dtype=torch.int64, device=dev)
+        d_gath = torch.zeros((world, nq), dtype=torch.int64, device=dev)
+        d_idx = torch.zeros(nq, dtype=torch.int32, device=dev)
+        d_b = torch.zeros(nq, dtype=torch.int16, device=dev)
+        d_s = torch.zeros(nq, dtype=torch.int16, device=dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        kern_ms = []
+
+        def bf_step(timed=False):
+            if timed:
+                ev0.record(stream)
+            bf.query_packed_device(d_q, d_packed, stream)
+            if timed:
+                ev1.record(stream)
+            if world > 1:
+                dist.all_gather_into_tensor(d_gath.view(-1), d_packed)
+                binding.merge_packed_device(local, d_gath, world, nq, d_idx, d_b, d_s, stream)
+            else:
+                binding.merge_packed_device(local, d_packed, 1, nq, d_idx, d_b, d_s, stream)
+
+        bf_step()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.bf_steps):
+            bf_step(timed=True)
+            torch.cuda.synchronize()
+            kern_ms.append(ev0.elapsed_time(ev1))
+        barrier()
+        dth = max_over_ranks(time.perf_counter() - t0)
+        gcmp = nq * nd * args.bf_steps / dth / 1e9
+        kms = float(np.mean(kern_ms))
+        kern_gcmp = nq * (hi - lo) / (kms * 1e-3) / 1e9
+        lane_ops = kern_gcmp * 1e9 * 16  # 8 v_xor_b32 + 8 v_bcnt_u32_b32 per comparison
+        hamming = {
+            "metric": "Hamming matches Gcmp/s (brute-force top-2)", "value": round(gcmp, 2), "unit": "Gcmp/s",
+            "queries": nq, "db_rows": nd, "rows_per_rank": hi - lo, "steps": args.bf_steps, "scaling": "strong",
+            "ms_per_step": round(dth / args.bf_steps * 1e3, 3),
+            "roofline": {"bound": "valu", "kernel": "k_bf_top2", "achieved": round(lane_ops / 1e12, 3),
+                         "peak": round(VALU_LANE_OPS / 1e12, 3), "unit": "T lane-ops/s",
+                         "frac": round(lane_ops / VALU_LANE_OPS, 4), "launch_ms": round(kms, 3),
+                         "db_stream_GBs": round((hi - lo) * 32 * ((nq + 255) // 256) / (kms * 1e-3) / 1e9, 1)},
+        }
+        if rank == 0 and not args.no_cpu and world == 1:
+            import oracle
+
+            sq, sd = 64, 500000
+            qh = d_q[:sq].cpu().numpy()
+            dbh = d_db[:sd].cpu().numpy()
+            t0 = time.perf_counter()
+            io, bo, so = oracle.bf_top2(qh, dbh)
+            tc = time.perf_counter() - t0
+            hamming["cpu_baseline"] = {"value": round(sq * sd / tc / 1e9, 3), "unit": "Gcmp/s", "cores": 1, "kind": "port",
+                                       "sample": "%d queries x %d rows, 4x popcount64 per pair" % (sq, sd)}
+            # same slice on the GPU must agree
+            bchk = binding.BruteForce(local)
+            bchk.set_database(dbh)
+            ig, bg, sg = bchk.query_top2(qh)
+            hamming["parity_checked"] = bool((ig == io).all() and (bg == bo).all() and (sg == so).all())
+
+    # ---- CPU baseline + parity spot check (rank 0, single GPU runs only) ----------------
+    cpu = None
+    parity = None
+    if rank == 0:
+        import oracle
+
+        e = oracle.Extractor(args.nfeatures, 1.2, 8, 20, 7, oracle.QUIRKS_FORK if args.preset == "fork" else oracle.QUIRKS_CANONICAL)
+        ko, do = e.extract(frames[0])
+        kg = d_kps[0, : counts[0]].cpu().numpy().view(binding.KP_DTYPE).reshape(-1)
+        dg = d_desc[0, : counts[0]].cpu().numpy()
+        parity = bool(len(kg) == len(ko) and (kg == ko).all() and (dg == do).all())
+        if not args.no_cpu and world == 1:
+            nc = min(args.cpu_frames, B)
+            t0 = time.perf_counter()
+            reps = 0
+            while reps < args.cpu_frames:
+                e.extract(frames[reps % nc])
+                reps += 1
+            tc = time.perf_counter() - t0
+            cpu = {"value": round(reps / tc, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": "%d frames of the same batch, single thread (the reference extracts on one tracking thread)" % reps}
+
+    if rank == 0:
+        out = {
+            "metric": "ORB extract frames/s (640x480, 1k feats)", "value": round(fps, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "ORBextractor::operator() over %d frames %dx%d per GPU per step, nFeatures=%d, 8 levels, scale 1.2, iniThFAST 20, minThFAST 7, preset %s"
+                                   % (B, W, H, args.nfeatures, args.preset),
+                       "batch_per_gpu": B, "keypoints_per_frame": round(nkp, 1)},
+            "roofline": roofline, "cpu_baseline": cpu, "parity_checked": parity, "hamming": hamming,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -191,6 +191,18 @@ int orb_bf_query_packed_device(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t*
 int orb_bf_merge_packed_device(int device, const uint64_t* d_gathered, int nshards, int nq, int32_t* d_best_idx,
                                uint16_t* d_best_dist, uint16_t* d_second_dist, void* stream);
 
+/* ---- measurement ------------------------------------------------------------ */
+
+/* Stage timing with HIP events recorded on the launch stream around the four
+ * stages of every extraction batch (pyramid, FAST cells, quadtree, describe).
+ * orb_get_stage_timings synchronises, writes the mean milliseconds per batch of
+ * each stage over the batches recorded since the last call (at most the last
+ * 64) into ms[0..3], their number into *nbatches, and clears the record.
+ * (No counterpart in the reference, which takes no timings.) */
+#define ORB_NUM_STAGES 4
+int orb_enable_stage_timing(orb_ctx* ctx, int on);
+int orb_get_stage_timings(orb_ctx* ctx, float ms[ORB_NUM_STAGES], int* nbatches);
+
 /* ---- misc ------------------------------------------------------------------ */
 const char* orb_last_error(void);
 const char* orb_version(void);

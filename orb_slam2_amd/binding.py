@@ -29,7 +29,7 @@ EXPORTS = [
     "orb_debug_get_fast_keys", "orb_resize", "orb_gaussian_blur", "orb_hamming", "orb_match_window",
     "orb_match_window_batch_device", "orb_match_projected", "orb_bf_create", "orb_bf_destroy", "orb_bf_set_database",
     "orb_bf_set_database_device", "orb_bf_query_top2", "orb_bf_query_packed_device", "orb_bf_merge_packed_device",
-    "orb_last_error", "orb_version",
+    "orb_enable_stage_timing", "orb_get_stage_timings", "orb_last_error", "orb_version",
 ]
 
 
@@ -148,6 +148,16 @@ class Context:
         _check(lib().orb_extract_batch_device(
             self.h, _dp(d_imgs), n, w, h, d_imgs.stride(1), C.c_int64(d_imgs.stride(0)), _dp(d_kps), _dp(d_desc), cap,
             _dp(d_counts), _stream(stream)))
+
+    def enable_stage_timing(self, on=True):
+        _check(lib().orb_enable_stage_timing(self.h, int(on)))
+
+    def stage_timings(self):
+        """Mean ms per batch of (pyramid, fast, quadtree, describe) since the last call, and the batch count."""
+        ms = (C.c_float * 4)()
+        n = C.c_int(0)
+        _check(lib().orb_get_stage_timings(self.h, ms, C.byref(n)))
+        return dict(pyramid=ms[0], fast=ms[1], quadtree=ms[2], describe=ms[3]), n.value
 
     def check_last_batch(self):
         _check(lib().orb_check_last_batch(self.h))

@@ -87,7 +87,12 @@ struct orb_ctx {
     int64_t lastFrameStride0 = 0;
     // matcher scratch lives in kernels_match.hip
     void* matchState = nullptr;
+    // stage timing: ring of event sets, one set (5 events) per recorded batch
+    bool timing = false;
+    std::vector<hipEvent_t> events;
+    int evCount = 0;
 };
+#define ORB_EV_RING 64
 
 void orb_match_state_free(void* p);
 
@@ -454,6 +459,7 @@ extern "C" void orb_destroy(orb_ctx* c) {
                       &c->dTmpB};
     for (DevBuf* b : bufs) b->release();
     if (c->matchState) orb_match_state_free(c->matchState);
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -535,10 +541,20 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
     c->lastImg0 = d_img0;
     c->lastStride0 = stride;
     c->lastFrameStride0 = frameStride;
+    hipEvent_t* ev = nullptr;
+    if (c->timing) {
+        ev = &c->events[(size_t)(c->evCount % ORB_EV_RING) * 5];
+        c->evCount++;
+        HIP_TRY(hipEventRecord(ev[0], st));
+    }
     if ((rc = orb_launch_pyramid(b))) return rc;
+    if (ev) HIP_TRY(hipEventRecord(ev[1], st));
     if ((rc = orb_launch_fast(b))) return rc;
+    if (ev) HIP_TRY(hipEventRecord(ev[2], st));
     if ((rc = orb_launch_quadtree(b))) return rc;
+    if (ev) HIP_TRY(hipEventRecord(ev[3], st));
     if ((rc = orb_launch_describe(b))) return rc;
+    if (ev) HIP_TRY(hipEventRecord(ev[4], st));
     return ORB_OK;
 }
 
@@ -553,6 +569,45 @@ static int read_error_flag(orb_ctx* c) {
                       (flag & 64) ? " caller keypoint capacity" : "");
         return ORB_ERR_CAPACITY;
     }
+    return ORB_OK;
+}
+
+extern "C" int orb_enable_stage_timing(orb_ctx* c, int on) {
+    if (!c) {
+        orb_set_error("null context");
+        return ORB_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->prm.device));
+    if (on && c->events.empty()) {
+        c->events.resize((size_t)ORB_EV_RING * 5);
+        for (hipEvent_t& e : c->events) HIP_TRY(hipEventCreate(&e));
+    }
+    c->timing = on != 0;
+    c->evCount = 0;
+    return ORB_OK;
+}
+
+extern "C" int orb_get_stage_timings(orb_ctx* c, float ms[ORB_NUM_STAGES], int* nbatches) {
+    if (!c || !ms || !nbatches) {
+        orb_set_error("orb_get_stage_timings: null argument");
+        return ORB_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->prm.device));
+    HIP_TRY(hipDeviceSynchronize());
+    const int n = std::min(c->evCount, ORB_EV_RING);
+    for (int s = 0; s < ORB_NUM_STAGES; s++) ms[s] = 0.f;
+    for (int i = 0; i < n; i++) {
+        hipEvent_t* ev = &c->events[(size_t)i * 5];
+        for (int s = 0; s < ORB_NUM_STAGES; s++) {
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, ev[s], ev[s + 1]));
+            ms[s] += t;
+        }
+    }
+    if (n > 0)
+        for (int s = 0; s < ORB_NUM_STAGES; s++) ms[s] /= n;
+    *nbatches = n;
+    c->evCount = 0;
     return ORB_OK;
 }
 
