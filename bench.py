@@ -24,7 +24,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, spec
-VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz: full-rate 32-bit integer lane-ops/s
+# 32-bit integer VALU ops (v_xor_b32, v_bcnt_u32_b32) retire 16 lanes per clock and SIMD on gfx950
+# (tools/valu_peak.hip measures 37.7-38.1 T lane-ops/s for either alone): 256 CUs x 4 SIMDs x 16 x 2.4 GHz.
+VALU_LANE_OPS = 256 * 4 * 16 * 2.4e9
 
 
 def level_geometry(w, h, nlevels, scale):

@@ -17,11 +17,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 #include "orb_internal.h"
 
-#define BF_QPL 4      // queries per lane
-#define BF_GROUP 4    // rows per inner step
 #define BF_NONE 0xFFFFu
 
 struct orb_bf {
@@ -38,6 +38,8 @@ struct orb_bf {
     void* d_out = nullptr;
     size_t outBytes = 0;
     hipStream_t stream = nullptr;
+    int residentBlocks = 0;  // workgroups of the scan kernel the device holds at once
+    int variant = -1;
 };
 
 #define HIP_TRY(call)                                                                                   \
@@ -93,17 +95,50 @@ static __device__ __forceinline__ void top2_update(uint32_t d, uint32_t row, uin
     }
 }
 
+// One group of GROUP rows against the lane's QPL queries.
+template <int QPL, int GROUP, bool MINRED>
+static __device__ __forceinline__ void bf_group(const uint32_t (&qv)[QPL][8], const Row256 (&rw)[GROUP], uint32_t rowBase,
+                                                uint32_t (&bd)[QPL], uint32_t (&bi)[QPL], uint32_t (&sd)[QPL]) {
+    uint32_t d[GROUP][QPL];
+    bool any = false;
+#pragma unroll
+    for (int g = 0; g < GROUP; g++) {
+#pragma unroll
+        for (int j = 0; j < QPL; j++) {
+            d[g][j] = hamming256(qv[j], rw[g]);
+            if (!MINRED) any |= d[g][j] < sd[j];
+        }
+    }
+    if (MINRED) {
+#pragma unroll
+        for (int j = 0; j < QPL; j++) {
+            uint32_t m = d[0][j];
+#pragma unroll
+            for (int g = 1; g < GROUP; g++) m = min(m, d[g][j]);
+            any |= m < sd[j];
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(any)) {
+#pragma unroll
+        for (int g = 0; g < GROUP; g++) {
+#pragma unroll
+            for (int j = 0; j < QPL; j++) top2_update(d[g][j], rowBase + g, bd[j], bi[j], sd[j]);
+        }
+    }
+}
+
+template <int QPL, int GROUP, bool PREFETCH, bool MINRED>
 __global__ __launch_bounds__(256) void k_bf_top2(const uint32_t* __restrict__ q, int nq,
                                                  const uint32_t* __restrict__ db, long long nd,
                                                  long long rowsPerChunk, long long globalBase,
                                                  unsigned long long* __restrict__ partial) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long qb = ((long long)blockIdx.x * 4 + wave) * (64 * BF_QPL);
+    const long long qb = ((long long)blockIdx.x * 4 + wave) * (64 * QPL);
     if (qb >= nq) return;
-    uint32_t qv[BF_QPL][8];
-    uint32_t bd[BF_QPL], sd[BF_QPL], bi[BF_QPL];
+    uint32_t qv[QPL][8];
+    uint32_t bd[QPL], sd[QPL], bi[QPL];
 #pragma unroll
-    for (int j = 0; j < BF_QPL; j++) {
+    for (int j = 0; j < QPL; j++) {
         long long qi = qb + j * 64 + lane;
         if (qi >= nq) qi = nq - 1;  // tail lanes compute on a valid row and are not written back
         const uint4* p = (const uint4*)(q + qi * 8);
@@ -117,36 +152,47 @@ __global__ __launch_bounds__(256) void k_bf_top2(const uint32_t* __restrict__ q,
     const long long r0 = (long long)blockIdx.y * rowsPerChunk;
     const long long r1 = (r0 + rowsPerChunk < nd) ? r0 + rowsPerChunk : nd;
     long long r = r0;
-    for (; r + BF_GROUP <= r1; r += BF_GROUP) {
-        const uint32_t* __restrict__ rows = db + r * 8;  // wave-uniform address: scalar loads
-        uint32_t d[BF_GROUP][BF_QPL];
-        Row256 rw[BF_GROUP];
+    if (PREFETCH) {
+        // two row buffers: the scalar loads of the next group are in flight while this group is compared
+        Row256 A[GROUP], B[GROUP];
+        if (r + GROUP <= r1) {
 #pragma unroll
-        for (int g = 0; g < BF_GROUP; g++) rw[g] = load_row(rows + g * 8);
-        bool any = false;
+            for (int g = 0; g < GROUP; g++) A[g] = load_row(db + (r + g) * 8);
+        }
+        while (r + 2 * GROUP <= r1) {
 #pragma unroll
-        for (int g = 0; g < BF_GROUP; g++) {
+            for (int g = 0; g < GROUP; g++) B[g] = load_row(db + (r + GROUP + g) * 8);
+            bf_group<QPL, GROUP, MINRED>(qv, A, (uint32_t)(r - r0), bd, bi, sd);
+            r += GROUP;
+            if (r + 2 * GROUP <= r1) {
 #pragma unroll
-            for (int j = 0; j < BF_QPL; j++) {
-                d[g][j] = hamming256(qv[j], rw[g]);
-                any |= d[g][j] < sd[j];
+                for (int g = 0; g < GROUP; g++) A[g] = load_row(db + (r + GROUP + g) * 8);
+                bf_group<QPL, GROUP, MINRED>(qv, B, (uint32_t)(r - r0), bd, bi, sd);
+                r += GROUP;
+            } else {
+#pragma unroll
+                for (int g = 0; g < GROUP; g++) A[g] = B[g];
             }
         }
-        if (__builtin_amdgcn_ballot_w64(any)) {
+        if (r + GROUP <= r1) {
+            bf_group<QPL, GROUP, MINRED>(qv, A, (uint32_t)(r - r0), bd, bi, sd);
+            r += GROUP;
+        }
+    } else {
+        for (; r + GROUP <= r1; r += GROUP) {
+            Row256 rw[GROUP];
 #pragma unroll
-            for (int g = 0; g < BF_GROUP; g++) {
-#pragma unroll
-                for (int j = 0; j < BF_QPL; j++) top2_update(d[g][j], (uint32_t)(r + g - r0), bd[j], bi[j], sd[j]);
-            }
+            for (int g = 0; g < GROUP; g++) rw[g] = load_row(db + (r + g) * 8);  // wave-uniform address: scalar loads
+            bf_group<QPL, GROUP, MINRED>(qv, rw, (uint32_t)(r - r0), bd, bi, sd);
         }
     }
     for (; r < r1; r++) {
         const Row256 row = load_row(db + r * 8);
 #pragma unroll
-        for (int j = 0; j < BF_QPL; j++) top2_update(hamming256(qv[j], row), (uint32_t)(r - r0), bd[j], bi[j], sd[j]);
+        for (int j = 0; j < QPL; j++) top2_update(hamming256(qv[j], row), (uint32_t)(r - r0), bd[j], bi[j], sd[j]);
     }
 #pragma unroll
-    for (int j = 0; j < BF_QPL; j++) {
+    for (int j = 0; j < QPL; j++) {
         const long long qi = qb + j * 64 + lane;
         if (qi < nq) {
             const unsigned long long idx =
@@ -156,6 +202,128 @@ __global__ __launch_bounds__(256) void k_bf_top2(const uint32_t* __restrict__ q,
         }
     }
 }
+
+// Variant that stages database rows in LDS: the scalar data cache sustains only
+// about one 64-byte miss per ~130 cycles per CU, which caps a scan that streams
+// its rows through scalar loads at under half the VALU rate.  Here the workgroup
+// copies TR rows per tile into LDS with one coalesced 16-byte load per thread
+// (two tiles in flight), and every wave reads the rows back as broadcast
+// ds_read_b128 (all lanes the same address: conflict-free), so the compare is
+// VGPR x VGPR and the row traffic rides the vector memory path.
+template <int QPL, int GROUP, int TR>
+__global__ __launch_bounds__(256) void k_bf_top2_lds(const uint32_t* __restrict__ q, int nq,
+                                                     const uint32_t* __restrict__ db, long long nd,
+                                                     long long rowsPerChunk, long long globalBase,
+                                                     unsigned long long* __restrict__ partial) {
+    static_assert(TR * 32 % (256 * 16) == 0, "tile must be a whole number of 16-byte loads per thread");
+    constexpr int LPT = TR * 32 / (256 * 16);  // 16-byte loads per thread and tile
+    __shared__ __attribute__((aligned(16))) uint32_t s_rows[2][TR * 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long qb = ((long long)blockIdx.x * 4 + wave) * (64 * QPL);
+    const bool active = qb < nq;   // inactive waves still help loading tiles and hit every barrier
+    if (!active) qb = 0;
+    uint32_t qv[QPL][8];
+    uint32_t bd[QPL], sd[QPL], bi[QPL];
+#pragma unroll
+    for (int j = 0; j < QPL; j++) {
+        long long qi = qb + j * 64 + lane;
+        if (qi >= nq) qi = nq - 1;
+        const uint4* p = (const uint4*)(q + qi * 8);
+        const uint4 lo = p[0], hi = p[1];
+        qv[j][0] = lo.x; qv[j][1] = lo.y; qv[j][2] = lo.z; qv[j][3] = lo.w;
+        qv[j][4] = hi.x; qv[j][5] = hi.y; qv[j][6] = hi.z; qv[j][7] = hi.w;
+        bd[j] = BF_NONE;
+        sd[j] = BF_NONE;
+        bi[j] = 0xFFFFFFFFu;
+    }
+    const long long r0 = (long long)blockIdx.y * rowsPerChunk;
+    const long long r1 = (r0 + rowsPerChunk < nd) ? r0 + rowsPerChunk : nd;
+    const long long lastByte = nd * 32 - 16;  // clamp tile loads that run past the database
+    const uint8_t* dbb = (const uint8_t*)db;
+    uint4 stage[LPT];
+    auto fetch = [&](long long tileRow) {
+#pragma unroll
+        for (int k = 0; k < LPT; k++) {
+            long long off = tileRow * 32 + ((long long)k * 256 + threadIdx.x) * 16;
+            if (off > lastByte) off = lastByte;
+            stage[k] = *(const uint4*)(dbb + off);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < LPT; k++) ((uint4*)s_rows[buf])[k * 256 + threadIdx.x] = stage[k];
+    };
+    if (r0 < r1) {
+        fetch(r0);
+        stash(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (long long t = r0; t < r1; t += TR) {
+        const bool more = t + TR < r1;
+        if (more) fetch(t + TR);
+        const int rowsHere = (int)((r1 - t < TR) ? r1 - t : TR);
+        if (active) {
+            const uint32_t* tile = s_rows[buf];
+            int r = 0;
+            for (; r + GROUP <= rowsHere; r += GROUP) {
+                Row256 rw[GROUP];
+#pragma unroll
+                for (int g = 0; g < GROUP; g++) rw[g] = load_row(tile + (r + g) * 8);
+                bf_group<QPL, GROUP, true>(qv, rw, (uint32_t)(t - r0) + r, bd, bi, sd);
+            }
+            for (; r < rowsHere; r++) {
+                const Row256 row = load_row(tile + r * 8);
+#pragma unroll
+                for (int j = 0; j < QPL; j++)
+                    top2_update(hamming256(qv[j], row), (uint32_t)(t - r0) + r, bd[j], bi[j], sd[j]);
+            }
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (!active) return;
+#pragma unroll
+    for (int j = 0; j < QPL; j++) {
+        const long long qi = qb + j * 64 + lane;
+        if (qi < nq) {
+            const unsigned long long idx =
+                (bd[j] == BF_NONE) ? 0xFFFFFFFFull : (unsigned long long)(globalBase + r0 + bi[j]) & 0xFFFFFFFFull;
+            partial[(long long)blockIdx.y * nq + qi] =
+                ((unsigned long long)bd[j] << 48) | ((unsigned long long)sd[j] << 32) | idx;
+        }
+    }
+}
+
+typedef void (*bf_kernel_t)(const uint32_t*, int, const uint32_t*, long long, long long, long long, unsigned long long*);
+struct BfVariant {
+    const char* name;
+    bf_kernel_t fn;
+    int qpl, group;
+};
+static const BfVariant kBfVariants[] = {
+    {"q4g4", k_bf_top2<4, 4, false, false>, 4, 4},
+    {"q4g4p", k_bf_top2<4, 4, true, false>, 4, 4},
+    {"q4g4m", k_bf_top2<4, 4, false, true>, 4, 4},
+    {"q4g4pm", k_bf_top2<4, 4, true, true>, 4, 4},
+    {"q8g2", k_bf_top2<8, 2, false, false>, 8, 2},
+    {"q8g2pm", k_bf_top2<8, 2, true, true>, 8, 2},
+    {"q8g4m", k_bf_top2<8, 4, false, true>, 8, 4},
+    {"q4g8m", k_bf_top2<4, 8, false, true>, 4, 8},
+    {"q2g8m", k_bf_top2<2, 8, false, true>, 2, 8},
+    {"q2g8pm", k_bf_top2<2, 8, true, true>, 2, 8},
+    {"q6g4pm", k_bf_top2<6, 4, true, true>, 6, 4},
+    {"L_q4g4t128", k_bf_top2_lds<4, 4, 128>, 4, 4},
+    {"L_q4g2t128", k_bf_top2_lds<4, 2, 128>, 4, 2},
+    {"L_q4g4t256", k_bf_top2_lds<4, 4, 256>, 4, 4},
+    {"L_q8g2t128", k_bf_top2_lds<8, 2, 128>, 8, 2},
+    {"L_q8g4t256", k_bf_top2_lds<8, 4, 256>, 8, 4},
+    {"L_q6g2t128", k_bf_top2_lds<6, 2, 128>, 6, 2},
+    {"L_q2g4t128", k_bf_top2_lds<2, 4, 128>, 2, 4},
+    {"L_q4g8t256", k_bf_top2_lds<4, 8, 256>, 4, 8},
+};
+#define BF_DEFAULT_VARIANT 17  // L_q2g4t128
 
 // Combine nshards packed candidates per query.  Inserting every shard's best
 // (distance, row) and second distance into one running top-2 equals scanning
@@ -283,18 +451,34 @@ extern "C" int orb_bf_set_database(orb_bf* bf, const uint8_t* db, int64_t n, int
     return ORB_OK;
 }
 
-// Chunks along the database so that the launch has a few thousand wavefronts.
-static int bf_chunks(int nq, int64_t nd, long long* rowsPerChunk) {
-    const long long qWaves = (nq + 64 * BF_QPL - 1) / (64 * BF_QPL);
-    long long chunks = (8192 + qWaves - 1) / qWaves;
-    const long long maxChunks = std::max<long long>(1, nd / 4096);  // keep chunks long enough to amortise set-up
-    chunks = std::max<long long>(1, std::min<long long>(std::min<long long>(chunks, maxChunks), 1024));
-    long long rpc = (nd + chunks - 1) / chunks;
-    rpc = (rpc + BF_GROUP - 1) / BF_GROUP * BF_GROUP;
-    if (rpc < BF_GROUP) rpc = BF_GROUP;
-    chunks = std::max<long long>(1, (nd + rpc - 1) / rpc);
+// Chunks along the database.  Every workgroup does the same amount of work, so
+// the launch runs in rounds of `resident` workgroups; the chunk count is chosen
+// so that the last round is (almost) full instead of leaving most of the chip
+// idle behind a few stragglers, while chunks stay long enough that the first
+// rows of a chunk (which update the top-2 state often) are a small share.
+static int bf_chunks(int nq, int64_t nd, int resident, int qpl, int group, long long* rowsPerChunk) {
+    const long long qBlocks = (nq + 256 * qpl - 1) / (256 * qpl);
+    const long long maxChunks = std::max<long long>(1, std::min<long long>(nd / 8192, 4096));
+    long long best = 1;
+    double bestEff = -1.0;
+    if (resident < 1) resident = 1;
+    for (int k = 1; k <= 8; k++) {
+        long long chunks = ((long long)k * resident) / qBlocks;
+        chunks = std::max<long long>(1, std::min(chunks, maxChunks));
+        const long long wgs = chunks * qBlocks;
+        const long long rounds = (wgs + resident - 1) / resident;
+        const double eff = (double)wgs / ((double)rounds * resident);
+        if (eff > bestEff + 0.02) {
+            bestEff = eff;
+            best = chunks;
+        }
+        if (eff >= 0.97) break;
+    }
+    long long rpc = (nd + best - 1) / best;
+    rpc = (rpc + group - 1) / group * group;
+    if (rpc < group) rpc = group;
     *rowsPerChunk = rpc;
-    return (int)chunks;
+    return (int)std::max<long long>(1, (nd + rpc - 1) / rpc);
 }
 
 extern "C" int orb_bf_query_packed_device(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t* d_packed, void* stream) {
@@ -305,13 +489,26 @@ extern "C" int orb_bf_query_packed_device(orb_bf* bf, const uint8_t* d_q, int nq
     if (nq == 0) return ORB_OK;
     HIP_TRY(hipSetDevice(bf->device));
     hipStream_t st = (hipStream_t)stream;
-    long long rpc = BF_GROUP;
-    const int chunks = bf_chunks(nq, bf->n, &rpc);
+    if (bf->variant < 0) {
+        // ORBHIP_BF_VARIANT selects a tuning variant of the scan kernel by name (development aid)
+        bf->variant = BF_DEFAULT_VARIANT;
+        const char* env = getenv("ORBHIP_BF_VARIANT");
+        if (env)
+            for (size_t i = 0; i < sizeof(kBfVariants) / sizeof(kBfVariants[0]); i++)
+                if (!strcmp(env, kBfVariants[i].name)) bf->variant = (int)i;
+        int perCu = 0, cus = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kBfVariants[bf->variant].fn, 256, 0));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, bf->device));
+        bf->residentBlocks = std::max(1, perCu) * std::max(1, cus);
+    }
+    const BfVariant& V = kBfVariants[bf->variant];
+    long long rpc = V.group;
+    const int chunks = bf_chunks(nq, bf->n, bf->residentBlocks, V.qpl, V.group, &rpc);
     int rc = bf_ensure(bf->d_partial, bf->partialBytes, (size_t)chunks * nq * 8);
     if (rc) return rc;
-    const int qBlocks = (nq + 256 * BF_QPL - 1) / (256 * BF_QPL);
+    const int qBlocks = (nq + 256 * V.qpl - 1) / (256 * V.qpl);
     if (bf->n > 0) {
-        hipLaunchKernelGGL(k_bf_top2, dim3(qBlocks, chunks), dim3(256), 0, st, (const uint32_t*)d_q, nq,
+        hipLaunchKernelGGL(V.fn, dim3(qBlocks, chunks), dim3(256), 0, st, (const uint32_t*)d_q, nq,
                            (const uint32_t*)bf->d_db, (long long)bf->n, rpc, (long long)bf->globalBase,
                            (unsigned long long*)bf->d_partial);
     } else {
