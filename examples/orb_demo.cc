@@ -1,0 +1,100 @@
+// Demo / integration test of the drop-in C++ classes: builds two Frames from
+// raw 8-bit images, matches them with ORBmatcher::SearchForInitialization and
+// ORBmatcher::SearchByProjection, and dumps everything to a binary file that
+// tests/test_gpu_cpp_dropin.py compares with the CPU oracle.
+//
+// usage: orb_demo <in.bin> <out.bin>
+//   in.bin : int32 w, h, nfeatures, window; float nnratio; then 2 * w*h bytes (frame A, frame B)
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../orb_slam2_amd/cpp/Frame.h"
+#include "../orb_slam2_amd/cpp/ORBextractor.h"
+#include "../orb_slam2_amd/cpp/ORBmatcher.h"
+
+using namespace ORB_SLAM2;
+
+template <typename T>
+static void put(FILE* f, const T* p, size_t n) { fwrite(p, sizeof(T), n, f); }
+
+int main(int argc, char** argv) {
+    if (argc < 3) return 2;
+    FILE* fi = fopen(argv[1], "rb");
+    if (!fi) return 3;
+    int hdr[4];
+    float nnratio;
+    if (fread(hdr, 4, 4, fi) != 4 || fread(&nnratio, 4, 1, fi) != 1) return 4;
+    const int w = hdr[0], h = hdr[1], nfeatures = hdr[2], window = hdr[3];
+    std::vector<unsigned char> a((size_t)w * h), b((size_t)w * h);
+    if (fread(a.data(), 1, a.size(), fi) != a.size() || fread(b.data(), 1, b.size(), fi) != b.size()) return 5;
+    fclose(fi);
+
+    try {
+        ORBextractor ext(nfeatures, 1.2f, 8, 20, 7);
+        cv::Mat imA(h, w, CV_8UC1, a.data()), imB(h, w, CV_8UC1, b.data());
+        cv::Mat K(3, 3, CV_32F), dist(4, 1, CV_32F);
+        for (int i = 0; i < 9; i++) K.at<float>(i / 3, i % 3) = 0.f;
+        K.at<float>(0, 0) = 500.f; K.at<float>(1, 1) = 500.f; K.at<float>(0, 2) = w / 2.f; K.at<float>(1, 2) = h / 2.f;
+        K.at<float>(2, 2) = 1.f;
+        for (int i = 0; i < 4; i++) dist.at<float>(i) = 0.f;
+        Frame F1(imA, 0.0, &ext, nullptr, K, dist, 40.f, 35.f);
+        std::vector<cv::Mat> pyrA = ext.mvImagePyramid;
+        for (cv::Mat& m : pyrA) m = m.clone();
+        Frame F2(imB, 1.0, &ext, nullptr, K, dist, 40.f, 35.f);
+
+        ORBmatcher matcher(nnratio, true);
+        std::vector<cv::Point2f> prev(F1.mvKeysUn.size());
+        for (size_t i = 0; i < prev.size(); i++) prev[i] = F1.mvKeysUn[i].pt;  // src/Tracking.cc:302-304
+        std::vector<int> m12;
+        const int nInit = matcher.SearchForInitialization(F1, F2, prev, m12, window);
+
+        // SearchByProjection: identity poses, one map point per F1 keypoint placed on its viewing ray at
+        // depth 2, so that it projects onto the keypoint; every 5th point has no observations.
+        cv::Mat T(4, 4, CV_32F);
+        for (int i = 0; i < 16; i++) T.at<float>(i / 4, i % 4) = (i / 4 == i % 4) ? 1.f : 0.f;
+        F1.SetPose(T);
+        F2.SetPose(T);
+        std::vector<MapPoint*> owned;
+        for (int i = 0; i < F1.N; i++) {
+            const float z = 2.f;
+            const float x = (F1.mvKeysUn[i].pt.x - Frame::cx) * Frame::invfx * z;
+            const float y = (F1.mvKeysUn[i].pt.y - Frame::cy) * Frame::invfy * z;
+            MapPoint* mp = new MapPoint(x, y, z, F1.mDescriptors.ptr<unsigned char>(i), (i % 5) ? 1 : 0);
+            owned.push_back(mp);
+            F1.mvpMapPoints[i] = mp;
+        }
+        const int nProj = matcher.SearchByProjection(F2, F1, 15.f, true);
+        std::vector<int> proj(F2.N, -1);
+        for (int i2 = 0; i2 < F2.N; i2++)
+            for (int i = 0; i < F1.N && F2.mvpMapPoints[i2]; i++)
+                if (F2.mvpMapPoints[i2] == F1.mvpMapPoints[i]) { proj[i2] = i; break; }
+        const std::vector<size_t> area = F2.GetFeaturesInArea(w / 2.f, h / 2.f, 60.f, 0, 2);
+        const int dd = F1.N > 1 ? ORBmatcher::DescriptorDistance(F1.mDescriptors.row(0), F1.mDescriptors.row(1)) : -1;
+
+        FILE* fo = fopen(argv[2], "wb");
+        if (!fo) return 6;
+        const int counts[8] = {F1.N, F2.N, nInit, nProj, (int)area.size(), dd, (int)pyrA.size(), 0};
+        put(fo, counts, 8);
+        put(fo, F1.mvKeys.data(), F1.mvKeys.size());
+        for (int i = 0; i < F1.N; i++) put(fo, F1.mDescriptors.ptr<unsigned char>(i), 32);
+        put(fo, F2.mvKeys.data(), F2.mvKeys.size());
+        for (int i = 0; i < F2.N; i++) put(fo, F2.mDescriptors.ptr<unsigned char>(i), 32);
+        put(fo, m12.data(), m12.size());
+        put(fo, prev.data(), prev.size());
+        put(fo, proj.data(), proj.size());
+        std::vector<int> area32(area.begin(), area.end());
+        put(fo, area32.data(), area32.size());
+        for (cv::Mat& m : pyrA) {
+            const int wh[2] = {m.cols, m.rows};
+            put(fo, wh, 2);
+            for (int r = 0; r < m.rows; r++) put(fo, m.ptr<unsigned char>(r), (size_t)m.cols);
+        }
+        fclose(fo);
+        for (MapPoint* p : owned) delete p;
+    } catch (const std::exception& e) {
+        fprintf(stderr, "orb_demo: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -156,7 +156,9 @@ int orb_match_window_batch_device(orb_ctx* ctx, int npairs, const orb_keypoint* 
  * query, the keypoint angle, the map point's descriptor and whether the map
  * point has observations; occupied2[i2] != 0 marks current-frame keypoints
  * that already hold an observed map point.  match2[i2] = index of the query
- * whose map point keypoint i2 holds afterwards, or -1. */
+ * whose map point keypoint i2 holds afterwards, -1 if the keypoint was never
+ * assigned, -2 if it was assigned and then cleared by the rotation check (the
+ * reference stores NULL there, :400). */
 int orb_match_projected(orb_ctx* ctx, const float* u, const float* v, const float* radius, const int* min_level,
                         const int* max_level, const float* qangle, const uint8_t* qdesc, const uint8_t* qobs, int nq,
                         const orb_keypoint* k2, const uint8_t* d2, int n2, int img_w, int img_h,

@@ -258,7 +258,7 @@ int searchByProjection(const float* u, const float* v, const float* radius, cons
         for (int i = 0; i < HISTO_LENGTH; i++) {
             if (i != ind1 && i != ind2 && i != ind3) {
                 for (int i2 : rotHist[i]) {
-                    match2[i2] = -1;
+                    match2[i2] = -2;  // the reference stores NULL here; -2 tells "cleared" from "never assigned"
                     nmatches--;
                 }
             }

@@ -1,0 +1,164 @@
+// Drop-in Frame (see Frame.h).
+#include "Frame.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <stdexcept>
+
+#include "../../include/orb_hip.h"
+
+namespace ORB_SLAM2 {
+
+long unsigned int Frame::nNextId = 0;
+bool Frame::mbInitialComputations = true;
+float Frame::cx, Frame::cy, Frame::fx, Frame::fy, Frame::invfx, Frame::invfy;
+float Frame::mnMinX, Frame::mnMinY, Frame::mnMaxX, Frame::mnMaxY;
+float Frame::mfGridElementWidthInv, Frame::mfGridElementHeightInv;
+unsigned Frame::msGridQuirks = ORB_Q_GRID_EXCLUSIVE | ORB_Q_WINDOW_CIRCULAR;
+
+Frame::Frame()
+    : mpORBvocabulary(nullptr), mpORBextractorLeft(nullptr), mpORBextractorRight(nullptr), mTimeStamp(0), mbf(0), mb(0),
+      mThDepth(0), N(0), mnId(0), mpReferenceKF(nullptr), mnScaleLevels(0), mfScaleFactor(0), mfLogScaleFactor(0),
+      mnImgWidth(0), mnImgHeight(0) {}
+
+// src/Frame.cc:11-51
+Frame::Frame(const Frame& f)
+    : mpORBvocabulary(f.mpORBvocabulary), mpORBextractorLeft(f.mpORBextractorLeft),
+      mpORBextractorRight(f.mpORBextractorRight), mTimeStamp(f.mTimeStamp), mK(f.mK.clone()),
+      mDistCoef(f.mDistCoef.clone()), mbf(f.mbf), mb(f.mb), mThDepth(f.mThDepth), N(f.N), mvKeys(f.mvKeys),
+      mvKeysRight(f.mvKeysRight), mvKeysUn(f.mvKeysUn), mvuRight(f.mvuRight), mvDepth(f.mvDepth),
+      mDescriptors(f.mDescriptors.clone()), mDescriptorsRight(f.mDescriptorsRight.clone()),
+      mvpMapPoints(f.mvpMapPoints), mvbOutlier(f.mvbOutlier), mnId(f.mnId), mpReferenceKF(f.mpReferenceKF),
+      mnScaleLevels(f.mnScaleLevels), mfScaleFactor(f.mfScaleFactor), mfLogScaleFactor(f.mfLogScaleFactor),
+      mvScaleFactors(f.mvScaleFactors), mvInvScaleFactors(f.mvInvScaleFactors), mvLevelSigma2(f.mvLevelSigma2),
+      mvInvLevelSigma2(f.mvInvLevelSigma2), mnImgWidth(f.mnImgWidth), mnImgHeight(f.mnImgHeight) {
+    for (int i = 0; i < FRAME_GRID_COLS; i++)
+        for (int j = 0; j < FRAME_GRID_ROWS; j++) mGrid[i][j] = f.mGrid[i][j];
+    if (!f.mTcw.empty()) SetPose(f.mTcw);
+}
+
+Frame::Frame(const cv::Mat& imGray, const double& timeStamp, ORBextractor* extractor, ORBVocabulary* voc, cv::Mat& K,
+             cv::Mat& distCoef, const float& bf, const float& thDepth)
+    : mpORBvocabulary(voc), mpORBextractorLeft(extractor), mpORBextractorRight(static_cast<ORBextractor*>(NULL)),
+      mTimeStamp(timeStamp), mK(K.clone()), mDistCoef(distCoef.clone()), mbf(bf), mThDepth(thDepth),
+      mpReferenceKF(nullptr) {
+    mnId = nNextId++;
+    mnScaleLevels = mpORBextractorLeft->GetLevels();
+    mfScaleFactor = mpORBextractorLeft->GetScaleFactor();
+    mfLogScaleFactor = (float)log(mfScaleFactor);
+    mvScaleFactors = mpORBextractorLeft->GetScaleFactors();
+    mvInvScaleFactors = mpORBextractorLeft->GetInverseScaleFactors();
+    mvLevelSigma2 = mpORBextractorLeft->GetScaleSigmaSquares();  // (the fork copies the inverse scale factors here)
+    mvInvLevelSigma2 = mpORBextractorLeft->GetInverseScaleSigmaSquares();
+    mnImgWidth = imGray.cols;
+    mnImgHeight = imGray.rows;
+
+    ExtractORB(0, imGray);
+
+    N = (int)mvKeys.size();
+    if (mvKeys.empty()) return;
+    UndistortKeyPoints();
+    mvuRight = std::vector<float>(N, -1);
+    mvDepth = std::vector<float>(N, -1);
+    mvpMapPoints = std::vector<MapPoint*>(N, static_cast<MapPoint*>(NULL));
+    mvbOutlier = std::vector<bool>(N, false);
+    if (mbInitialComputations) {
+        ComputeImageBounds(imGray);
+        mfGridElementWidthInv = static_cast<float>(FRAME_GRID_COLS) / (mnMaxX - mnMinX);
+        mfGridElementHeightInv = static_cast<float>(FRAME_GRID_ROWS) / (mnMaxY - mnMinY);
+        if (!K.empty()) {
+            fx = K.at<float>(0, 0);
+            fy = K.at<float>(1, 1);
+            cx = K.at<float>(0, 2);
+            cy = K.at<float>(1, 2);
+            invfx = 1.0f / fx;
+            invfy = 1.0f / fy;
+        }
+        mbInitialComputations = false;
+    }
+    mb = fx != 0.f ? mbf / fx : 0.f;
+    AssignFeaturesToGrid();
+}
+
+void Frame::ExtractORB(int flag, const cv::Mat& im) {
+    if (flag == 0)
+        (*mpORBextractorLeft)(im, cv::Mat(), mvKeys, mDescriptors);
+    else
+        (*mpORBextractorRight)(im, cv::Mat(), mvKeysRight, mDescriptorsRight);
+}
+
+void Frame::SetPose(cv::Mat Tcw) { mTcw = Tcw.clone(); }
+
+// Lens distortion is outside the front end's scope: keypoints are taken as undistorted.
+void Frame::UndistortKeyPoints() {
+    if (!mDistCoef.empty()) {
+        for (int i = 0; i < mDistCoef.rows * mDistCoef.cols; i++)
+            if (mDistCoef.at<float>(i) != 0.f)
+                throw std::runtime_error("Frame: non-zero distortion coefficients are not supported by this front end");
+    }
+    mvKeysUn = mvKeys;
+}
+
+void Frame::ComputeImageBounds(const cv::Mat& imLeft) {
+    mnMinX = 0.0f;
+    mnMaxX = (float)imLeft.cols;
+    mnMinY = 0.0f;
+    mnMaxY = (float)imLeft.rows;
+}
+
+bool Frame::PosInGrid(const cv::KeyPoint& kp, int& posX, int& posY) {
+    posX = (int)round((kp.pt.x - mnMinX) * mfGridElementWidthInv);
+    posY = (int)round((kp.pt.y - mnMinY) * mfGridElementHeightInv);
+    if (posX < 0 || posX >= FRAME_GRID_COLS || posY < 0 || posY >= FRAME_GRID_ROWS) return false;
+    return true;
+}
+
+void Frame::AssignFeaturesToGrid() {
+    int nReserve = (int)(0.5f * N / (FRAME_GRID_COLS * FRAME_GRID_ROWS));
+    for (unsigned int i = 0; i < FRAME_GRID_COLS; i++)
+        for (unsigned int j = 0; j < FRAME_GRID_ROWS; j++) mGrid[i][j].reserve(nReserve);
+    for (int i = 0; i < N; i++) {
+        const cv::KeyPoint& kp = mvKeysUn[i];
+        int nGridPosX, nGridPosY;
+        if (PosInGrid(kp, nGridPosX, nGridPosY)) mGrid[nGridPosX][nGridPosY].push_back(i);
+    }
+}
+
+std::vector<size_t> Frame::GetFeaturesInArea(const float& x, const float& y, const float& r, const int minLevel,
+                                             const int maxLevel) const {
+    std::vector<size_t> vIndices;
+    vIndices.reserve(N);
+    const bool excl = (msGridQuirks & ORB_Q_GRID_EXCLUSIVE) != 0;
+    const bool circ = (msGridQuirks & ORB_Q_WINDOW_CIRCULAR) != 0;
+    const int nMinCellX = std::max(0, (int)floor((x - mnMinX - r) * mfGridElementWidthInv));
+    if (nMinCellX >= FRAME_GRID_COLS) return vIndices;
+    const int nMaxCellX = std::min((int)FRAME_GRID_COLS - 1, (int)ceil((x - mnMinX + r) * mfGridElementWidthInv));
+    if (nMaxCellX < 0) return vIndices;
+    const int nMinCellY = std::max(0, (int)floor((y - mnMinY - r) * mfGridElementHeightInv));
+    if (excl ? nMinCellY > FRAME_GRID_ROWS : nMinCellY >= FRAME_GRID_ROWS) return vIndices;
+    const int nMaxCellY = std::min((int)FRAME_GRID_ROWS - 1, (int)ceil((y - mnMinY + r) * mfGridElementHeightInv));
+    if (nMaxCellY < 0) return vIndices;
+    const bool bCheckLevels = (minLevel >= 0) || (maxLevel >= 0);
+    const int endX = excl ? nMaxCellX : nMaxCellX + 1, endY = excl ? nMaxCellY : nMaxCellY + 1;
+    for (int ix = nMinCellX; ix < endX; ix++) {
+        for (int iy = nMinCellY; iy < endY; iy++) {
+            const std::vector<size_t>& vCell = mGrid[ix][iy];
+            for (size_t j = 0, jend = vCell.size(); j < jend; j++) {
+                const cv::KeyPoint& kpUn = mvKeysUn[vCell[j]];
+                if (bCheckLevels) {
+                    if (kpUn.octave < minLevel) continue;
+                    if (maxLevel >= 0)
+                        if (kpUn.octave > maxLevel) continue;
+                }
+                const float distx = kpUn.pt.x - x;
+                const float disty = kpUn.pt.y - y;
+                if (circ ? (distx * distx + disty * disty < r * r) : (fabs(distx) < r && fabs(disty) < r))
+                    vIndices.push_back(vCell[j]);
+            }
+        }
+    }
+    return vIndices;
+}
+
+}  // namespace ORB_SLAM2

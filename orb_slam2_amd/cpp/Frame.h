@@ -1,0 +1,84 @@
+// Drop-in for the part of include/Frame.h of the reference that the ORB front
+// end touches: the monocular constructor, ExtractORB, the 64x48 bucket grid
+// with GetFeaturesInArea, and the public members ORBmatcher reads.  Pose
+// graph, bag-of-words and stereo members are kept as declarations so that the
+// class stays source-compatible with its callers.
+#ifndef FRAME_H
+#define FRAME_H
+
+#include <cstddef>
+#include <vector>
+
+#include "ORBextractor.h"
+#include "cv_compat.h"
+
+#ifdef ORB_SLAM2_FULL_TREE
+#include "KeyFrame.h"
+#include "MapPoint.h"
+#include "ORBVocabulary.h"
+#else
+#include "MapPointCompat.h"
+namespace ORB_SLAM2 {
+class KeyFrame;
+struct ORBVocabulary;  // opaque here
+}  // namespace ORB_SLAM2
+#endif
+
+namespace ORB_SLAM2 {
+
+#define FRAME_GRID_ROWS 48
+#define FRAME_GRID_COLS 64
+
+class Frame {
+public:
+    Frame();
+    Frame(const Frame& frame);
+    // Monocular constructor, include/Frame.h:31, src/Frame.cc:53-69 (with the tail the fork lost:
+    // keypoint count, undistorted copy, map-point slots, image bounds, grid).
+    Frame(const cv::Mat& imGray, const double& timeStamp, ORBextractor* extractor, ORBVocabulary* voc, cv::Mat& K,
+          cv::Mat& distCoef, const float& bf, const float& thDepth);
+
+    void ExtractORB(int flag, const cv::Mat& im);  // src/Frame.cc:71-77
+    void SetPose(cv::Mat Tcw);
+    bool PosInGrid(const cv::KeyPoint& kp, int& posX, int& posY);
+    // src/Frame.cc:86-144.  Host-side accessor for callers that want the index list itself;
+    // the Search* kernels run the same query on the device.
+    std::vector<size_t> GetFeaturesInArea(const float& x, const float& y, const float& r, const int minLevel = -1,
+                                          const int maxLevel = -1) const;
+
+public:
+    ORBVocabulary* mpORBvocabulary;
+    ORBextractor *mpORBextractorLeft, *mpORBextractorRight;
+    double mTimeStamp;
+    cv::Mat mK;
+    static float fx, fy, cx, cy, invfx, invfy;
+    cv::Mat mDistCoef;
+    float mbf, mb, mThDepth;
+    int N;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysRight, mvKeysUn;
+    std::vector<float> mvuRight, mvDepth;
+    cv::Mat mDescriptors, mDescriptorsRight;
+    std::vector<MapPoint*> mvpMapPoints;
+    std::vector<bool> mvbOutlier;
+    static float mfGridElementWidthInv, mfGridElementHeightInv;
+    std::vector<std::size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
+    cv::Mat mTcw;
+    static long unsigned int nNextId;
+    long unsigned int mnId;
+    KeyFrame* mpReferenceKF;
+    int mnScaleLevels;
+    float mfScaleFactor, mfLogScaleFactor;
+    std::vector<float> mvScaleFactors, mvInvScaleFactors, mvLevelSigma2, mvInvLevelSigma2;
+    static float mnMinX, mnMaxX, mnMinY, mnMaxY;
+    static bool mbInitialComputations;
+    static unsigned msGridQuirks;  // ORB_Q_GRID_EXCLUSIVE | ORB_Q_WINDOW_CIRCULAR as selected (fork by default)
+    int mnImgWidth, mnImgHeight;
+
+private:
+    void UndistortKeyPoints();
+    void ComputeImageBounds(const cv::Mat& imLeft);
+    void AssignFeaturesToGrid();
+};
+
+}  // namespace ORB_SLAM2
+#endif

@@ -1,0 +1,27 @@
+// Stand-alone stand-in for the three MapPoint accessors that
+// ORBmatcher::SearchByProjection reads (src/ORBmatcher.cc:310,337,346).  When
+// the drop-in is compiled inside the reference tree, define
+// ORB_SLAM2_FULL_TREE and the real MapPoint.h is used instead.
+#pragma once
+#include "cv_compat.h"
+
+namespace ORB_SLAM2 {
+class MapPoint {
+public:
+    MapPoint(float x, float y, float z, const unsigned char desc[32], int nObs) : mnObs(nObs) {
+        mWorldPos.create(3, 1, CV_32F);
+        mWorldPos.at<float>(0) = x;
+        mWorldPos.at<float>(1) = y;
+        mWorldPos.at<float>(2) = z;
+        mDescriptor.create(1, 32, CV_8U);
+        memcpy(mDescriptor.data, desc, 32);
+    }
+    cv::Mat GetWorldPos() { return mWorldPos.clone(); }
+    cv::Mat GetDescriptor() { return mDescriptor.clone(); }
+    int Observations() { return mnObs; }
+
+private:
+    cv::Mat mWorldPos, mDescriptor;
+    int mnObs;
+};
+}  // namespace ORB_SLAM2

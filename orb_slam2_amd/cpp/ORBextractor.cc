@@ -1,0 +1,110 @@
+// Drop-in ORBextractor over the C ABI of liborbhip (see ORBextractor.h).
+#include "ORBextractor.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/orb_hip.h"
+
+namespace ORB_SLAM2 {
+
+static unsigned gQuirks = ORB_QUIRKS_FORK;
+static int gDevice = 0;
+static bool gEnvRead = false;
+
+static void readEnv() {
+    if (gEnvRead) return;
+    gEnvRead = true;
+    if (const char* q = getenv("ORBHIP_QUIRKS")) gQuirks = (unsigned)strtoul(q, nullptr, 0);
+    if (const char* d = getenv("ORBHIP_DEVICE")) gDevice = atoi(d);
+}
+
+void ORBextractor::SetDefaults(unsigned quirks, int device) {
+    gEnvRead = true;
+    gQuirks = quirks;
+    gDevice = device;
+}
+
+static void fail(const char* what) { throw std::runtime_error(std::string(what) + ": " + orb_last_error()); }
+
+ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)
+    : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST) {
+    readEnv();
+    mQuirks = gQuirks;
+    mDevice = gDevice;
+    // The tables only depend on the constructor arguments; a small context provides them
+    // (the device context is re-created on the first frame, sized for that frame).
+    EnsureContext(640, 480);
+    mvScaleFactor.resize(nlevels);
+    mvInvScaleFactor.resize(nlevels);
+    mvLevelSigma2.resize(nlevels);
+    mvInvLevelSigma2.resize(nlevels);
+    mnFeaturesPerLevel.resize(nlevels);
+    umax.resize(16);
+    if (orb_get_tables(mpCtx, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(),
+                       mvInvLevelSigma2.data(), mnFeaturesPerLevel.data(), umax.data()))
+        fail("orb_get_tables");
+    mvImagePyramid.resize(nlevels);
+}
+
+ORBextractor::~ORBextractor() { orb_destroy(mpCtx); }
+
+orb_ctx* ORBextractor::EnsureContext(int width, int height) {
+    if (mpCtx && width <= mCtxW && height <= mCtxH) return mpCtx;
+    if (mpCtx) orb_destroy(mpCtx);
+    mpCtx = nullptr;
+    orb_params p;
+    p.nfeatures = nfeatures;
+    p.scale_factor = (float)scaleFactor;
+    p.nlevels = nlevels;
+    p.ini_th_fast = iniThFAST;
+    p.min_th_fast = minThFAST;
+    p.max_width = width;
+    p.max_height = height;
+    p.max_batch = 1;
+    p.device = mDevice;
+    p.quirks = mQuirks;
+    if (orb_create(&p, &mpCtx)) fail("orb_create");
+    mCtxW = width;
+    mCtxH = height;
+    return mpCtx;
+}
+
+void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints,
+                              cv::OutputArray _descriptors) {
+    if (_image.empty()) return;  // src/ORBextractor.cc:451-452
+    cv::Mat image = _image.getMat();
+    assert(image.type() == CV_8UC1);
+    EnsureContext(image.cols, image.rows);
+    const int cap = orb_max_keypoints_per_frame(mpCtx);
+    static_assert(sizeof(cv::KeyPoint) == sizeof(orb_keypoint), "cv::KeyPoint layout");
+    mKpBuf.resize((size_t)cap * sizeof(orb_keypoint));
+    mDescBuf.resize((size_t)cap * 32);
+    int n = 0;
+    if (orb_extract(mpCtx, image.data, image.cols, image.rows, (int)image.step, (orb_keypoint*)mKpBuf.data(),
+                    mDescBuf.data(), cap, &n))
+        fail("orb_extract");
+    _keypoints.clear();
+    _keypoints.resize(n);
+    if (n) memcpy((void*)_keypoints.data(), mKpBuf.data(), (size_t)n * sizeof(orb_keypoint));
+    if (n == 0) {
+        _descriptors.release();  // :468-469
+    } else {
+        _descriptors.create(n, 32, CV_8U);
+        cv::Mat d = _descriptors.getMat();
+        for (int i = 0; i < n; i++) memcpy(d.ptr<unsigned char>(i), mDescBuf.data() + (size_t)i * 32, 32);
+    }
+    if (mbKeepPyramid) {
+        for (int l = 0; l < nlevels; l++) {
+            int w = 0, h = 0;
+            if (orb_get_pyramid_level(mpCtx, 0, l, nullptr, 0, &w, &h)) fail("orb_get_pyramid_level");
+            mvImagePyramid[l].create(h, w, CV_8UC1);
+            if (orb_get_pyramid_level(mpCtx, 0, l, mvImagePyramid[l].data, (int)mvImagePyramid[l].step, &w, &h))
+                fail("orb_get_pyramid_level");
+        }
+    }
+}
+
+}  // namespace ORB_SLAM2

@@ -1,0 +1,70 @@
+// Drop-in for include/ORBextractor.h of the reference: same class name,
+// namespace, constructor, operator() and getters.  The work is done by the
+// HIP kernels of liborbhip through the C ABI (include/orb_hip.h); this class
+// only converts between the OpenCV-style containers and plain buffers.
+#ifndef ORBEXTRACTOR_H
+#define ORBEXTRACTOR_H
+
+#include <vector>
+
+#include "cv_compat.h"
+
+struct orb_ctx;
+
+namespace ORB_SLAM2 {
+
+class ORBextractor {
+public:
+    enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+    // include/ORBextractor.h:36, src/ORBextractor.cc:369-436
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+    ~ORBextractor();
+    ORBextractor(const ORBextractor&) = delete;
+    ORBextractor& operator=(const ORBextractor&) = delete;
+
+    // include/ORBextractor.h:39, src/ORBextractor.cc:448-509.  The mask is ignored, as in the reference.
+    // An empty image returns silently; a failure inside the GPU library throws std::runtime_error.
+    void operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint>& keypoints,
+                    cv::OutputArray descriptors);
+
+    int inline GetLevels() { return nlevels; }
+    float inline GetScaleFactor() { return (float)scaleFactor; }
+    std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
+    std::vector<float> inline GetInverseScaleFactors() { return mvInvScaleFactor; }
+    std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
+    std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+    // Level images of the last frame (the ROI part of the reference's padded buffers),
+    // downloaded after every extraction unless SetKeepPyramid(false) was called.
+    std::vector<cv::Mat> mvImagePyramid;
+
+    // ---- additions (no counterpart in the reference) -------------------------------
+    void SetKeepPyramid(bool keep) { mbKeepPyramid = keep; }
+    // Behaviour preset and device for extractors constructed afterwards
+    // (ORB_QUIRKS_FORK by default; also read from ORBHIP_QUIRKS / ORBHIP_DEVICE).
+    static void SetDefaults(unsigned quirks, int device);
+    orb_ctx* Context() { return mpCtx; }  // for ORBmatcher, which shares the device state
+    orb_ctx* EnsureContext(int width, int height);
+
+protected:
+    int nfeatures;
+    double scaleFactor;  // double member as in the reference
+    int nlevels;
+    int iniThFAST;
+    int minThFAST;
+    std::vector<int> mnFeaturesPerLevel;
+    std::vector<int> umax;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+
+    orb_ctx* mpCtx = nullptr;
+    int mCtxW = 0, mCtxH = 0;
+    bool mbKeepPyramid = true;
+    unsigned mQuirks;
+    int mDevice;
+    std::vector<unsigned char> mKpBuf, mDescBuf;
+};
+
+}  // namespace ORB_SLAM2
+
+#endif

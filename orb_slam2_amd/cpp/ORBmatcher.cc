@@ -1,0 +1,158 @@
+// Drop-in ORBmatcher over the C ABI of liborbhip (see ORBmatcher.h).
+#include "ORBmatcher.h"
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/orb_hip.h"
+
+namespace ORB_SLAM2 {
+
+const int ORBmatcher::TH_HIGH = 100;
+const int ORBmatcher::TH_LOW = 50;
+const int ORBmatcher::HISTO_LENGTH = 30;
+
+static void fail(const char* what) { throw std::runtime_error(std::string(what) + ": " + orb_last_error()); }
+
+ORBmatcher::ORBmatcher(float nnratio, bool checkOri) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+int ORBmatcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b) {
+    return orb_hamming(a.ptr<unsigned char>(), b.ptr<unsigned char>());
+}
+
+// Descriptors of a frame as one contiguous n x 32 block (cv::Mat rows may be strided).
+static const unsigned char* packed(const cv::Mat& d, std::vector<unsigned char>& tmp) {
+    if (d.empty()) return nullptr;
+    if (d.step == 32) return d.data;
+    tmp.resize((size_t)d.rows * 32);
+    for (int i = 0; i < d.rows; i++) memcpy(tmp.data() + (size_t)i * 32, d.ptr<unsigned char>(i), 32);
+    return tmp.data();
+}
+
+int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, std::vector<cv::Point2f>& vbPrevMatched,
+                                        std::vector<int>& vnMatches12, int windowSize) {
+    const int n1 = (int)F1.mvKeysUn.size(), n2 = (int)F2.mvKeysUn.size();
+    vnMatches12 = std::vector<int>(n1, -1);
+    if (n1 == 0) return 0;
+    if ((int)vbPrevMatched.size() < n1) throw std::invalid_argument("SearchForInitialization: vbPrevMatched too short");
+    orb_ctx* ctx = F2.mpORBextractorLeft ? F2.mpORBextractorLeft->Context() : F1.mpORBextractorLeft->Context();
+    std::vector<unsigned char> t1, t2;
+    static_assert(sizeof(cv::KeyPoint) == sizeof(orb_keypoint), "cv::KeyPoint layout");
+    static_assert(sizeof(cv::Point2f) == 8, "cv::Point2f layout");
+    int nmatches = 0;
+    if (orb_match_window(ctx, (const orb_keypoint*)F1.mvKeysUn.data(), packed(F1.mDescriptors, t1), n1,
+                         (const orb_keypoint*)F2.mvKeysUn.data(), packed(F2.mDescriptors, t2), n2, F2.mnImgWidth,
+                         F2.mnImgHeight, (float*)vbPrevMatched.data(), vnMatches12.data(), windowSize, mfNNratio,
+                         mbCheckOrientation ? 1 : 0, &nmatches))
+        fail("orb_match_window");
+    return nmatches;
+}
+
+int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono) {
+    // Pose algebra of src/ORBmatcher.cc:289-300 on 4x4 float matrices (sums accumulated in double and
+    // rounded once, as cv::gemm does for CV_32F).
+    auto T = [](const cv::Mat& m, int r, int c) { return (double)m.at<float>(r, c); };
+    const cv::Mat& Tc = CurrentFrame.mTcw;
+    const cv::Mat& Tl = LastFrame.mTcw;
+    float twc[3], tlc[3];
+    for (int i = 0; i < 3; i++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += -T(Tc, k, i) * T(Tc, k, 3);  // -Rcw^T * tcw
+        twc[i] = (float)s;
+    }
+    for (int i = 0; i < 3; i++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += T(Tl, i, k) * (double)twc[k];
+        tlc[i] = (float)(s + T(Tl, i, 3));
+    }
+    const bool bForward = tlc[2] > CurrentFrame.mb && !bMono;
+    const bool bBackward = -tlc[2] > CurrentFrame.mb && !bMono;
+
+    std::vector<float> u, v, radius, qangle;
+    std::vector<int> lmin, lmax, src;
+    std::vector<unsigned char> qdesc, qobs;
+    for (int i = 0; i < LastFrame.N; i++) {
+        MapPoint* pMP = LastFrame.mvpMapPoints[i];
+        if (!pMP) continue;
+        if (LastFrame.mvbOutlier[i]) continue;
+        cv::Mat x3Dw = pMP->GetWorldPos();
+        float xc3[3];
+        for (int r = 0; r < 3; r++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += T(Tc, r, k) * (double)x3Dw.at<float>(k);
+            xc3[r] = (float)(s + T(Tc, r, 3));
+        }
+        const float xc = xc3[0], yc = xc3[1];
+        const float invzc = (float)(1.0 / xc3[2]);
+        if (invzc < 0) continue;
+        const float uu = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
+        const float vv = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
+        if (uu < CurrentFrame.mnMinX || uu > CurrentFrame.mnMaxX) continue;
+        if (vv < CurrentFrame.mnMinY || vv > CurrentFrame.mnMaxY) continue;
+        const int nLastOctave = LastFrame.mvKeys[i].octave;
+        u.push_back(uu);
+        v.push_back(vv);
+        radius.push_back(th * CurrentFrame.mvScaleFactors[nLastOctave]);
+        if (bForward) {
+            lmin.push_back(nLastOctave);
+            lmax.push_back(-1);
+        } else if (bBackward) {
+            lmin.push_back(0);
+            lmax.push_back(nLastOctave);
+        } else {
+            lmin.push_back(nLastOctave - 1);
+            lmax.push_back(nLastOctave + 1);
+        }
+        qangle.push_back(LastFrame.mvKeysUn[i].angle);
+        cv::Mat dMP = pMP->GetDescriptor();
+        qdesc.insert(qdesc.end(), dMP.ptr<unsigned char>(), dMP.ptr<unsigned char>() + 32);
+        qobs.push_back(pMP->Observations() > 0 ? 1 : 0);
+        src.push_back(i);
+    }
+    const int nq = (int)u.size(), n2 = CurrentFrame.N;
+    if (nq == 0 || n2 == 0) return 0;
+    std::vector<unsigned char> occ(n2, 0), t2;
+    for (int i2 = 0; i2 < n2; i2++)
+        if (CurrentFrame.mvpMapPoints[i2] && CurrentFrame.mvpMapPoints[i2]->Observations() > 0) occ[i2] = 1;
+    std::vector<int> match2(n2, -1);
+    int nmatches = 0;
+    orb_ctx* ctx = CurrentFrame.mpORBextractorLeft->Context();
+    if (orb_match_projected(ctx, u.data(), v.data(), radius.data(), lmin.data(), lmax.data(), qangle.data(),
+                            qdesc.data(), qobs.data(), nq, (const orb_keypoint*)CurrentFrame.mvKeysUn.data(),
+                            packed(CurrentFrame.mDescriptors, t2), n2, CurrentFrame.mnImgWidth,
+                            CurrentFrame.mnImgHeight, occ.data(), match2.data(), TH_HIGH, mbCheckOrientation ? 1 : 0,
+                            &nmatches))
+        fail("orb_match_projected");
+    for (int i2 = 0; i2 < n2; i2++) {
+        if (match2[i2] >= 0)
+            CurrentFrame.mvpMapPoints[i2] = LastFrame.mvpMapPoints[src[match2[i2]]];
+        else if (match2[i2] == -2)  // assigned, then rejected by the rotation histogram (:400)
+            CurrentFrame.mvpMapPoints[i2] = static_cast<MapPoint*>(NULL);
+    }
+    return nmatches;
+}
+
+// src/ORBmatcher.cc:413-454 (host helper kept for callers; the kernels carry their own copy).
+void ORBmatcher::ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        if (s > max1) {
+            max3 = max2; max2 = max1; max1 = s;
+            ind3 = ind2; ind2 = ind1; ind1 = i;
+        } else if (s > max2) {
+            max3 = max2; max2 = s;
+            ind3 = ind2; ind2 = i;
+        } else if (s > max3) {
+            max3 = s; ind3 = i;
+        }
+    }
+    if (max2 < 0.1f * (float)max1) {
+        ind2 = -1; ind3 = -1;
+    } else if (max3 < 0.1f * (float)max1) {
+        ind3 = -1;
+    }
+}
+
+}  // namespace ORB_SLAM2

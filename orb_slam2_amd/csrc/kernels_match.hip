@@ -387,7 +387,7 @@ __global__ __launch_bounds__(64) void k_match_projected(const float* __restrict_
         for (int i = lane; i < nq; i += 64) {
             const int bin = qBin[i];
             if (bin < 0 || bin == ind1 || bin == ind2 || bin == ind3) continue;
-            match2[qIdx2[i]] = -1;  // :400-401, once per list entry
+            match2[qIdx2[i]] = -2;  // :400-401, once per list entry (-2: assigned, then cleared)
             removed++;
         }
 #pragma unroll

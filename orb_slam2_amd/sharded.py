@@ -1,0 +1,88 @@
+"""Multi-GPU host logic: one process per GPU (torch.distributed, backend
+"nccl" = RCCL on ROCm; "gloo" in the CPU tests).
+
+Two ways the ORB front end shards, neither present in the reference (which is
+single-threaded on this path):
+
+* frames of a batch are independent -> contiguous block partition, no
+  collective on the data path (`shard_range`);
+* the brute-force descriptor database is row-sharded; every rank scans its
+  rows for all queries and the per-query packed top-2 words
+  (best << 48 | second << 32 | global row) are exchanged with ONE all-gather
+  and merged on every rank (`ShardedBruteForce`).
+
+The scan and the merge are injected: the product passes the HIP entry points
+of liborbhip (`hip_backend`), the CPU tests pass stand-ins built on the oracle.
+"""
+import numpy as np
+
+
+def shard_range(n, rank, world):
+    """Contiguous block [lo, hi) of n units owned by `rank` of `world`."""
+    return rank * n // world, (rank + 1) * n // world
+
+
+def pack_top2(best_dist, second_dist, idx):
+    """uint64 words best << 48 | second << 32 | idx (0xFFFF / 0xFFFFFFFF = none)."""
+    b = np.asarray(best_dist, np.uint64)
+    s = np.asarray(second_dist, np.uint64)
+    i = np.asarray(idx, np.int64).astype(np.uint64) & np.uint64(0xFFFFFFFF)
+    return (b << np.uint64(48)) | (s << np.uint64(32)) | i
+
+
+def unpack_top2(packed):
+    p = np.asarray(packed).view(np.uint64)
+    best = (p >> np.uint64(48)).astype(np.uint16)
+    second = ((p >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.uint16)
+    idx = (p & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    idx = np.where(best == 0xFFFF, -1, idx).astype(np.int32)
+    return idx, best, second
+
+
+class ShardedBruteForce:
+    """Row-sharded brute-force top-2 over a process group.
+
+    scan(queries) -> packed int64 tensor [nq] for this rank's rows (global row numbers)
+    merge(gathered [world, nq]) -> (idx, best, second)
+    """
+
+    def __init__(self, scan, merge, group=None):
+        self.scan, self.merge, self.group = scan, merge, group
+
+    def query(self, queries):
+        import torch
+        import torch.distributed as dist
+
+        packed = self.scan(queries)
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world == 1:
+            gathered = packed.reshape(1, -1)
+        else:
+            gathered = torch.empty((world, packed.numel()), dtype=packed.dtype, device=packed.device)
+            dist.all_gather_into_tensor(gathered.view(-1), packed.contiguous(), group=self.group)
+        return self.merge(gathered)
+
+
+def hip_backend(db_shard_device, global_base, device):
+    """scan/merge callables over liborbhip for `ShardedBruteForce` (device tensors in and out)."""
+    import torch
+
+    from . import binding
+
+    bf = binding.BruteForce(device)
+    bf.set_database_device(db_shard_device, global_base)
+
+    def scan(d_q):
+        out = torch.empty(d_q.shape[0], dtype=torch.int64, device=d_q.device)
+        bf.query_packed_device(d_q, out)
+        return out
+
+    def merge(gathered):
+        world, nq = gathered.shape
+        idx = torch.empty(nq, dtype=torch.int32, device=gathered.device)
+        best = torch.empty(nq, dtype=torch.int16, device=gathered.device)
+        second = torch.empty(nq, dtype=torch.int16, device=gathered.device)
+        binding.merge_packed_device(device, gathered, world, nq, idx, best, second)
+        return idx, best, second
+
+    return scan, merge, bf

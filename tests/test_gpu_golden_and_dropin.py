@@ -1,0 +1,159 @@
+"""GPU: (1) the HIP path reproduces the committed golden fixtures; (2) the
+drop-in C++ classes (ORBextractor / Frame / ORBmatcher with the reference's
+signatures, orb_slam2_amd/cpp) driven by examples/orb_demo agree with the
+oracle; (3) size-independent properties at the benchmark's full sizes."""
+import glob
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from orb_slam2_amd.synth import frame_seed, synth_descriptors, synth_queries, synth_scene
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from orb_slam2_amd import binding
+
+    binding.lib()
+    return binding
+
+
+def test_golden_extraction_gpu(hip):
+    for f in sorted(glob.glob(os.path.join(G, "extract_*.npz"))):
+        z = np.load(f)
+        w, h = int(z["w"]), int(z["h"])
+        c = hip.Context(int(z["nfeatures"]), 1.2, int(z["nlevels"]), 20, 7, w, h, 1, 0, int(z["quirks"]))
+        k, d = c.extract(synth_scene(w, h, int(z["seed"])))
+        assert len(k) == len(z["keypoints"]), f
+        assert (k == z["keypoints"]).all() and (d == z["descriptors"]).all(), f
+        c.close()
+
+
+def test_golden_matching_and_bruteforce_gpu(hip):
+    for f in sorted(glob.glob(os.path.join(G, "match_*.npz"))):
+        z = np.load(f)
+        w, h = int(z["w"]), int(z["h"])
+        c = hip.Context(2000, 1.2, 8, 20, 7, w, h, 1, 0, int(z["quirks"]))
+        prev = np.stack([z["k1"]["x"], z["k1"]["y"]], axis=1).astype(np.float32)
+        n, m12, pout = c.match_window(z["k1"], z["d1"], z["k2"], z["d2"], w, h, prev, 100, 0.9, True)
+        assert n == int(z["nmatches"]) and (m12 == z["matches12"]).all() and (pout == z["prev_out"]).all(), f
+        c.close()
+    z = np.load(os.path.join(G, "bruteforce_256x4096.npz"))
+    db = synth_descriptors(4096, int(z["db_seed"]))
+    q = synth_queries(db, 256, int(z["q_seed"]))
+    db[3000:3010] = db[5:15]
+    q[:10] = db[5:15]
+    bf = hip.BruteForce(0)
+    bf.set_database(db)
+    idx, b, s = bf.query_top2(q)
+    assert (idx == z["idx"]).all() and (b == z["best"]).all() and (s == z["second"]).all()
+
+
+def _f32(x):
+    return np.float32(x)
+
+
+@pytest.mark.parametrize("preset", ["fork", "canonical"])
+def test_cpp_dropin_demo(oracle, tmp_path, preset):
+    exe = os.path.join(ROOT, "examples", "orb_demo")
+    assert os.path.exists(exe), "examples/orb_demo is built by __graft_entry__.build()"
+    quirks = oracle.QUIRKS_FORK if preset == "fork" else oracle.QUIRKS_CANONICAL
+    w, h, nf, window, ratio = 640, 480, 1000, 100, 0.9
+    a = synth_scene(w, h, frame_seed(1, 7))
+    b = synth_scene(w, h, frame_seed(1, 7), shift=(3, 2), noise_seed=4711)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<iiiif", w, h, nf, window, ratio))
+        f.write(a.tobytes())
+        f.write(b.tobytes())
+    env = dict(os.environ, ORBHIP_QUIRKS=str(quirks))
+    subprocess.check_call([exe, fin, fout], env=env, timeout=120)
+    raw = open(fout, "rb").read()
+    cnt = np.frombuffer(raw, np.int32, 8)
+    n1, n2, n_init, n_proj, n_area, dd, nlev = (int(v) for v in cnt[:7])
+    off = 32
+    KP = oracle.KP_DTYPE
+
+    def take(dtype, n):
+        nonlocal off
+        arr = np.frombuffer(raw, dtype, n, off)
+        off += arr.nbytes
+        return arr
+
+    k1 = take(KP, n1); d1 = take(np.uint8, n1 * 32).reshape(n1, 32)
+    k2 = take(KP, n2); d2 = take(np.uint8, n2 * 32).reshape(n2, 32)
+    m12 = take(np.int32, n1); prev = take(np.float32, 2 * n1).reshape(n1, 2)
+    proj = take(np.int32, n2); area = take(np.int32, n_area)
+    e = oracle.Extractor(nf, 1.2, 8, 20, 7, quirks)
+    ko2, do2 = e.extract(b)
+    ko1, do1 = e.extract(a)
+    assert (k1 == ko1).all() and (d1 == do1).all() and (k2 == ko2).all() and (d2 == do2).all()
+    for l in range(nlev):  # mvImagePyramid of frame A (the oracle extracted A last)
+        wl, hl = (int(v) for v in take(np.int32, 2))
+        lvl = take(np.uint8, wl * hl).reshape(hl, wl)
+        assert (lvl == e.level(l)).all(), "mvImagePyramid[%d]" % l
+    prev0 = np.stack([ko1["x"], ko1["y"]], axis=1).astype(np.float32)
+    no, mo, po = oracle.search_for_initialization(ko1, do1, ko2, do2, w, h, prev0, window, ratio, True, quirks)
+    assert n_init == no and (m12 == mo).all() and (prev == po).all()
+    assert dd == oracle.hamming(do1[0], do1[1])
+    assert (area == oracle.features_in_area(ko2, w, h, w / 2.0, h / 2.0, 60.0, 0, 2, quirks)).all()
+    # SearchByProjection: re-do the demo's float arithmetic (identity pose, depth 2, fx = fy = 500)
+    fx = _f32(500.0); cx = _f32(w / 2.0); cy = _f32(h / 2.0); inv = _f32(1.0) / fx; z = _f32(2.0)
+    X = (ko1["x"] - cx) * inv * z
+    Y = (ko1["y"] - cy) * inv * z
+    invz = _f32(1.0 / 2.0)
+    u = fx * X * invz + cx
+    v = fx * Y * invz + cy
+    scale = e.tables()["scale"]
+    radius = _f32(15.0) * scale[ko1["octave"]]
+    qobs = (np.arange(n1) % 5 != 0).astype(np.uint8)
+    npo, match2 = oracle.search_by_projection(u, v, radius, ko1["octave"] - 1, ko1["octave"] + 1, ko1["angle"], do1, qobs,
+                                              ko2, do2, w, h, None, 100, True, quirks)
+    assert n_proj == npo
+    assert (proj == np.where(match2 >= 0, match2, -1)).all()
+    assert npo > 100
+
+
+def test_properties_at_full_sizes(hip):
+    """Config-scale checks that need no oracle run: (a) every descriptor's distance to itself is 0 and the
+    brute-force scan of a set against itself returns the identity with second >= best; (b) extraction is
+    deterministic and batch-invariant (frame f of a 64-frame batch equals the same frame alone);
+    (c) keypoints lie inside the image, level-major, with the per-level lower bound of the quota rule."""
+    import torch
+
+    n = 200000
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    d_db = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    bf = hip.BruteForce(0)
+    bf.set_database_device(d_db, 0)
+    q = d_db[::97].contiguous()
+    packed = torch.zeros(q.shape[0], dtype=torch.int64, device="cuda")
+    bf.query_packed_device(q, packed)
+    torch.cuda.synchronize()
+    p = packed.cpu().numpy().view(np.uint64)
+    assert ((p >> np.uint64(48)) == 0).all()
+    assert ((p & np.uint64(0xFFFFFFFF)) == np.arange(0, n, 97, dtype=np.uint64)).all()
+    assert (((p >> np.uint64(32)) & np.uint64(0xFFFF)) > 0).all()
+
+    B = 64
+    c = hip.Context(1000, 1.2, 8, 20, 7, 640, 480, B, 0, 0x1F)
+    imgs = [synth_scene(640, 480, frame_seed(1, 100 + f)) for f in range(B)]
+    res = c.extract_batch(imgs)
+    res2 = c.extract_batch(imgs)
+    per = c.tables()["per_level"]
+    for f in (0, 31, 63):
+        k, d = res[f]
+        k1, d1 = c.extract(imgs[f])
+        assert (k == k1).all() and (d == d1).all() and (k == res2[f][0]).all()
+        assert (np.diff(k["octave"]) >= 0).all()
+        assert (k["x"] >= 0).all() and (k["x"] < 640).all() and (k["y"] >= 0).all() and (k["y"] < 480).all()
+        assert len(k) >= 900 and len(k) <= c.cap
+        assert (k["angle"] >= 0).all() and (k["angle"] <= 360).all()
+    c.close()
