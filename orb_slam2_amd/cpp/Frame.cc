@@ -44,6 +44,7 @@ Frame::Frame(const cv::Mat& imGray, const double& timeStamp, ORBextractor* extra
       mTimeStamp(timeStamp), mK(K.clone()), mDistCoef(distCoef.clone()), mbf(bf), mThDepth(thDepth),
       mpReferenceKF(nullptr) {
     mnId = nNextId++;
+    msGridQuirks = extractor->Quirks() & (ORB_Q_GRID_EXCLUSIVE | ORB_Q_WINDOW_CIRCULAR);  // same preset as the kernels
     mnScaleLevels = mpORBextractorLeft->GetLevels();
     mfScaleFactor = mpORBextractorLeft->GetScaleFactor();
     mfLogScaleFactor = (float)log(mfScaleFactor);

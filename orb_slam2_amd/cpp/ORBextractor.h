@@ -45,6 +45,7 @@ public:
     // (ORB_QUIRKS_FORK by default; also read from ORBHIP_QUIRKS / ORBHIP_DEVICE).
     static void SetDefaults(unsigned quirks, int device);
     orb_ctx* Context() { return mpCtx; }  // for ORBmatcher, which shares the device state
+    unsigned Quirks() const { return mQuirks; }
     orb_ctx* EnsureContext(int width, int height);
 
 protected:
