@@ -35,9 +35,12 @@
 
 struct MatchLds {
     uint32_t sorted[M_MAXKP];      // bucket << 16 | keypoint index, ascending (index < 65536)
+    float2 xy[M_MAXKP];            // keypoint position, by sorted position
+    uint8_t oct[M_MAXKP];          // keypoint octave, by sorted position
     uint16_t cellStart[M_CELLS + 2];
     uint16_t matchedDist[M_MAXKP]; // vMatchedDistance (0xFFFF = INT_MAX) / occupancy flag for the projected search
     int16_t owner[M_MAXKP];        // vnMatches21 / query that owns the keypoint
+    uint16_t cand[M_MAXKP];        // sorted positions that passed the window test of the current query
     int hist[ORB_HISTO];
 };
 
@@ -53,6 +56,10 @@ static __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
     return v;
 }
+
+struct Window {
+    int x0, x1, y0, y1;  // bucket ranges [x0,x1) x [y0,y1); empty when x1 <= x0
+};
 
 // Sort the frame's keypoints into bucket order and build bucket start offsets.
 // Bucket assignment as the Frame constructor does it (PosInGrid): rounded
@@ -100,11 +107,49 @@ static __device__ void grid_build(MatchLds& S, const orb_keypoint* __restrict__ 
     }
     wave_lds_sync();
     *nIn = S.cellStart[M_CELLS];
+    for (int p = lane; p < *nIn; p += 64) {
+        const orb_keypoint kp = k2[S.sorted[p] & 0xFFFFu];
+        S.xy[p] = make_float2(kp.x, kp.y);
+        S.oct[p] = (uint8_t)(kp.octave < 0 ? 255 : (kp.octave > 254 ? 254 : kp.octave));
+    }
+    wave_lds_sync();
 }
 
-struct Window {
-    int x0, x1, y0, y1;  // bucket ranges [x0,x1) x [y0,y1); empty when x1 <= x0
-};
+// Window query: collects into S.cand the sorted positions of the keypoints GetFeaturesInArea would
+// return (src/Frame.cc:110-136), in its order.  The buckets of the window's columns form one
+// contiguous slice of the sorted array; rows outside [y0, y1) are skipped.  Returns the count.
+static __device__ int window_candidates(MatchLds& S, const Window& w, float x, float y, float r, int minLevel,
+                                        int maxLevel, bool circ, int lane) {
+    if (w.x1 <= w.x0 || w.y1 <= w.y0) return 0;
+    const int lo = S.cellStart[w.x0 * ORB_GRID_ROWS + w.y0];
+    const int hi = S.cellStart[(w.x1 - 1) * ORB_GRID_ROWS + w.y1];
+    const bool checkLevels = minLevel >= 0 || maxLevel >= 0;
+    const float r2 = __fmul_rn(r, r);
+    int n = 0;
+    for (int base = lo; base < hi; base += 64) {
+        const int p = base + lane;
+        bool ok = false;
+        if (p < hi) {
+            const int iy = (int)(S.sorted[p] >> 16) % ORB_GRID_ROWS;
+            ok = iy >= w.y0 && iy < w.y1;
+            if (ok && checkLevels) {
+                const int o = S.oct[p];
+                if (o < minLevel) ok = false;
+                if (maxLevel >= 0 && o > maxLevel) ok = false;
+            }
+            if (ok) {
+                const float2 q = S.xy[p];
+                const float dx = __fsub_rn(q.x, x), dy = __fsub_rn(q.y, y);
+                ok = circ ? (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < r2) : (fabsf(dx) < r && fabsf(dy) < r);
+            }
+        }
+        const unsigned long long b = __ballot(ok);
+        if (ok) S.cand[n + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)p;
+        n += __popcll(b);
+    }
+    wave_lds_sync();
+    return n;
+}
 
 // Bucket range of GetFeaturesInArea(x, y, r), src/Frame.cc:91-112.
 static __device__ __forceinline__ Window window_cells(float x, float y, float r, float wInv, float hInv, bool excl) {
@@ -125,17 +170,6 @@ static __device__ __forceinline__ Window window_cells(float x, float y, float r,
     if (w.y0 > ORB_GRID_ROWS) w.y0 = ORB_GRID_ROWS;
     if (w.y1 < w.y0) w.y1 = w.y0;
     return w;
-}
-
-static __device__ __forceinline__ bool in_window(const orb_keypoint& kp, float x, float y, float r, int minLevel,
-                                                 int maxLevel, bool circ) {
-    if (minLevel >= 0 || maxLevel >= 0) {
-        if (kp.octave < minLevel) return false;
-        if (maxLevel >= 0 && kp.octave > maxLevel) return false;
-    }
-    const float dx = __fsub_rn(kp.x, x), dy = __fsub_rn(kp.y, y);
-    if (circ) return __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < __fmul_rn(r, r);
-    return fabsf(dx) < r && fabsf(dy) < r;
 }
 
 static __device__ __forceinline__ int hamming_rows(const uint4 a0, const uint4 a1, const uint8_t* __restrict__ b) {
@@ -227,21 +261,18 @@ __global__ __launch_bounds__(64) void k_match_window(const orb_keypoint* __restr
         // per-lane running (distance << 16 | array position) minimum and second-smallest distance
         uint32_t best = 0xFFFFFFFFu;
         uint32_t second = 0xFFFFu;
-        for (int ix = w.x0; ix < w.x1; ix++) {
-            const int lo = S.cellStart[ix * ORB_GRID_ROWS + w.y0], hi = S.cellStart[ix * ORB_GRID_ROWS + w.y1];
-            for (int p = lo + lane; p < hi; p += 64) {
-                const int i2 = (int)(S.sorted[p] & 0xFFFFu);
-                const orb_keypoint kp2 = k2[i2];
-                if (!in_window(kp2, x, y, window, kp1.octave, kp1.octave, circ)) continue;
-                const uint32_t dist = (uint32_t)hamming_rows(a0, a1, d2 + (int64_t)i2 * 32);
-                if ((uint32_t)S.matchedDist[i2] <= dist) continue;  // :63-64
-                const uint32_t key = (dist << 16) | (uint32_t)p;
-                if (key < best) {
-                    second = min(second, best >> 16);
-                    best = key;
-                } else {
-                    second = min(second, dist);
-                }
+        const int nc = window_candidates(S, w, x, y, window, kp1.octave, kp1.octave, circ, lane);
+        for (int c = lane; c < nc; c += 64) {
+            const int p = S.cand[c];
+            const int i2 = (int)(S.sorted[p] & 0xFFFFu);
+            const uint32_t dist = (uint32_t)hamming_rows(a0, a1, d2 + (int64_t)i2 * 32);
+            if ((uint32_t)S.matchedDist[i2] <= dist) continue;  // :63-64
+            const uint32_t key = (dist << 16) | (uint32_t)p;
+            if (key < best) {
+                second = min(second, best >> 16);
+                best = key;
+            } else {
+                second = min(second, dist);
             }
         }
         // wave reduction: smallest key; second = smallest distance among everything but that one entry
@@ -346,16 +377,13 @@ __global__ __launch_bounds__(64) void k_match_projected(const float* __restrict_
         const Window w = window_cells(x, y, r, wInv, hInv, excl);
         const uint4 a0 = ((const uint4*)(qdesc + (int64_t)i * 32))[0], a1 = ((const uint4*)(qdesc + (int64_t)i * 32))[1];
         uint32_t best = 0xFFFFFFFFu;
-        for (int ix = w.x0; ix < w.x1; ix++) {
-            const int lo = S.cellStart[ix * ORB_GRID_ROWS + w.y0], hi = S.cellStart[ix * ORB_GRID_ROWS + w.y1];
-            for (int p = lo + lane; p < hi; p += 64) {
-                const int i2 = (int)(S.sorted[p] & 0xFFFFu);
-                const orb_keypoint kp2 = k2[i2];
-                if (!in_window(kp2, x, y, r, lmin, lmax, circ)) continue;
-                if (S.matchedDist[i2]) continue;  // :345-347
-                const uint32_t dist = (uint32_t)hamming_rows(a0, a1, d2 + (int64_t)i2 * 32);
-                best = min(best, (dist << 16) | (uint32_t)p);
-            }
+        const int nc = window_candidates(S, w, x, y, r, lmin, lmax, circ, lane);
+        for (int c = lane; c < nc; c += 64) {
+            const int p = S.cand[c];
+            const int i2 = (int)(S.sorted[p] & 0xFFFFu);
+            if (S.matchedDist[i2]) continue;  // :345-347
+            const uint32_t dist = (uint32_t)hamming_rows(a0, a1, d2 + (int64_t)i2 * 32);
+            best = min(best, (dist << 16) | (uint32_t)p);
         }
         const uint32_t wbest = wave_min_u32(best);
         if (wbest == 0xFFFFFFFFu) continue;

@@ -7,9 +7,9 @@
 
 #include "quadtree_core.h"
 
-#define QT_THREADS 256
+#define QT_MAX_THREADS 1024
 
-__global__ __launch_bounds__(QT_THREADS) void k_quadtree(const OrbGeom* __restrict__ g, int nframes,
+__global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __restrict__ g, int nframes,
                                                         const uint32_t* __restrict__ cellKeys,
                                                         const int* __restrict__ cellCount, int* __restrict__ cellOff,
                                                         unsigned long long* __restrict__ sortBuf,
@@ -22,12 +22,13 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const OrbGeom* __restri
     const int nlevels = g->nlevels;
     const int frame = blockIdx.x / nlevels, level = blockIdx.x - frame * nlevels;
     const OrbLevel& L = g->lv[level];
-    const int t = threadIdx.x, T = QT_THREADS;
+    const int t = threadIdx.x, T = (int)blockDim.x;
     const int nCells = L.nCols * L.nRows;
     const int64_t cell0 = (int64_t)frame * g->cellsPerFrame + L.cellBase;
     const int* cc = cellCount + cell0;
     int* off = cellOff + (int64_t)frame * (g->cellsPerFrame + nlevels) + L.cellBase + level;  // nCells + 1 entries
-    unsigned long long* sorted = sortBuf + (int64_t)frame * g->keysPerFrame + L.keyBase;
+    unsigned long long* sorted = sortBuf + ((int64_t)frame * g->keysPerFrame + L.keyBase) * 2;
+    unsigned long long* tmp = sorted + L.keyCap;
     unsigned long long* info = keyInfo + (int64_t)frame * g->keysPerFrame + L.keyBase;
 
     for (int c = t; c < nCells; c += T) off[c] = cc[c];
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const OrbGeom* __restri
             const int x = 3 + cj * L.wCell + (int)(key & 0xff);  // relative to the 16-pixel border, as :864-865
             const int y = 3 + ci * L.hCell + (int)((key >> 8) & 0xff);
             const int r = base + k;
-            sorted[r] = ((unsigned long long)qt_code(x, y, L.nIni, L.hX, height) << 32) | (unsigned)r;
+            tmp[r] = ((unsigned long long)qt_code(x, y, L.nIni, L.hX, height) << 32) | (unsigned)r;
             info[r] = (unsigned long long)(unsigned)x | ((unsigned long long)(unsigned)y << 16) |
                       ((unsigned long long)(key >> 16) << 32);
         }
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const OrbGeom* __restri
     __syncthreads();
     int count = 0;
     if (n > 0) {
-        qt_sort(sorted, n);
+        qt_sort_keys(tmp, sorted, n, L.nIni, &sh);
         QtWork w;
         w.sorted = sorted;
         w.nodeCap = L.nodeCap;
@@ -88,9 +89,9 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const OrbGeom* __restri
             count = L.outCap;
         }
         const int64_t ob = (int64_t)frame * g->outCapFrame + L.outBase;
+        qt_select_all(sorted, info, list, count, w.scanA, &sh);
         for (int i = t; i < count; i += T) {
-            const int r = qt_select(sorted, info, list[i]);
-            const unsigned long long ki = info[r];
+            const unsigned long long ki = info[w.scanA[i]];
             selXY[ob + i] = (uint32_t)ki;
             selScore[ob + i] = (int)(ki >> 32);
         }
@@ -103,7 +104,9 @@ __global__ __launch_bounds__(QT_THREADS) void k_quadtree(const OrbGeom* __restri
 
 int orb_launch_quadtree(const OrbBatch& b) {
     const OrbGeom& g = *b.h_geom;
-    hipLaunchKernelGGL(k_quadtree, dim3(b.nframes * g.nlevels), dim3(QT_THREADS), 0, (hipStream_t)b.stream, b.d_geom,
+    // large levels (4K frames hand ~1e5 keys to the quadtree) get a full 1024-thread workgroup
+    const int threads = g.lv[0].keyCap > 400000 ? 1024 : 256;
+    hipLaunchKernelGGL(k_quadtree, dim3(b.nframes * g.nlevels), dim3(threads), 0, (hipStream_t)b.stream, b.d_geom,
                        b.nframes, b.d_cellKeys, b.d_cellCount, b.d_cellOff, b.d_sort, b.d_keyInfo, b.d_nodes, b.d_ints,
                        b.d_selXY, b.d_selScore, b.d_levelCount, b.d_levelKeys, b.d_error);
     hipError_t e = hipGetLastError();

@@ -384,7 +384,7 @@ static int ensure_buffers(orb_ctx* c, int n) {
     if ((rc = c->dCellKeys.ensure((size_t)n * g.cellsPerFrame * g.cellCap * 4))) return rc;
     if ((rc = c->dCellCount.ensure((size_t)n * g.cellsPerFrame * 4))) return rc;
     if ((rc = c->dCellOff.ensure((size_t)n * (g.cellsPerFrame + g.nlevels) * 4))) return rc;
-    if ((rc = c->dSort.ensure((size_t)n * g.keysPerFrame * 8 + 8))) return rc;
+    if ((rc = c->dSort.ensure((size_t)n * g.keysPerFrame * 16 + 16))) return rc;
     if ((rc = c->dInfo.ensure((size_t)n * g.keysPerFrame * 8 + 8))) return rc;
     if ((rc = c->dNodes.ensure((size_t)n * g.nodesPerFrame * 2 * sizeof(OrbNode)))) return rc;
     if ((rc = c->dInts.ensure(((size_t)n * g.nodesPerFrame * 9 + (size_t)n * g.nlevels * 4) * 4))) return rc;

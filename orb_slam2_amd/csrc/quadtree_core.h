@@ -27,19 +27,35 @@
 #define QT_TID 0
 #define QT_NT 1
 #define QT_FDIV(a, b) ((a) / (b))
+#define QT_ATOMIC_ADD(p, v) qt_host_fetch_add((p), (v))
+#define QT_ATOMIC_MAX64(p, v) (*(p) = (*(p) > (v)) ? *(p) : (v))
+static inline int qt_host_fetch_add(int* p, int v) {
+    const int o = *p;
+    *p = o + v;
+    return o;
+}
 #else
 #define QT_FN static __device__ __forceinline__
 #define QT_BARRIER() __syncthreads()
 #define QT_TID ((int)threadIdx.x)
 #define QT_NT ((int)blockDim.x)
 #define QT_FDIV(a, b) __fdiv_rn((a), (b))
+#define QT_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#define QT_ATOMIC_MAX64(p, v) atomicMax((p), (v))
 #endif
 
 #define QT_NOMORE 0x100
 #define QT_DEPTH(n) ((n).depthFlags & 0xff)
 
+#define QT_BINS 4096      // buckets of the key sort
+#define QT_SMALL_BIN 40   // buckets up to this size are sorted by one thread
+
 struct QtShared {
     int part[1024];  // per-thread partial sums of the block scan
+    int binStart[QT_BINS + 1];
+    int binCursor[QT_BINS];
+    int nBig;
+    unsigned long long best64;
     int total;
     int nL, prevSize, nToExpand, seqCounter, nRec, finish, fine, stop, err;
 };
@@ -88,26 +104,40 @@ QT_FN int qt_lower_bound(const unsigned long long* s, int lo, int hi, uint32_t k
 }
 
 // Exclusive prefix sum of a[0..n) in place; a[n] and sh->total receive the sum.
+// Each thread sums a contiguous chunk; the per-thread sums are scanned inside
+// each wavefront with shuffles and across wavefronts through LDS.
 QT_FN void qt_scan(int* a, int n, QtShared* sh) {
     const int T = QT_NT, t = QT_TID;
     const int chunk = (n + T - 1) / T;
     const int b = t * chunk, e = (b + chunk < n) ? b + chunk : n;
     int s = 0;
     for (int i = b; i < e; i++) s += a[i];
-    sh->part[t] = s;
-    QT_BARRIER();
-    if (t == 0) {
-        int run = 0;
-        for (int i = 0; i < T; i++) {
-            const int v = sh->part[i];
-            sh->part[i] = run;
-            run += v;
-        }
-        sh->total = run;
-        a[n] = run;
+#ifdef ORB_HOST_EMU
+    int run = 0;
+    sh->total = s;
+    a[n] = s;
+#else
+    const int lane = t & 63, wv = t >> 6, nw = (T + 63) >> 6;
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
     }
+    if (lane == 63) sh->part[wv] = incl;
     QT_BARRIER();
-    int run = sh->part[t];
+    int wprefix = 0, total = 0;
+    for (int i = 0; i < nw; i++) {
+        const int v = sh->part[i];
+        if (i < wv) wprefix += v;
+        total += v;
+    }
+    int run = wprefix + incl - s;
+    if (t == 0) {
+        sh->total = total;
+        a[n] = total;
+    }
+#endif
     for (int i = b; i < e; i++) {
         const int v = a[i];
         a[i] = run;
@@ -396,4 +426,101 @@ QT_FN int qt_select(const unsigned long long* sorted, const unsigned long long* 
         }
     }
     return bestRank;
+}
+
+// Sorts the n (code << 32 | rank) entries of `tmp` into `sorted`, ascending.
+// Entries are first bucketed by the leading bits of the quadtree path (one
+// histogram + one scatter over all keys, LDS counters), which already puts
+// every bucket into its final slice; buckets are then ordered internally, small
+// ones by one thread each, large ones by the whole workgroup.  Entries are
+// unique, so the result does not depend on the order atomics were served in.
+QT_FN void qt_sort_keys(const unsigned long long* tmp, unsigned long long* sorted, int n, int nIni, QtShared* sh) {
+    const int T = QT_NT, t = QT_TID;
+    const uint32_t maxCode = ((uint32_t)nIni << (2 * ORB_CODE_DEPTH)) - 1u;  // nIni <= 16
+    int bits = 0;
+    while ((maxCode >> bits) != 0u && bits < 32) bits++;
+    const int shift = bits > 12 ? bits - 12 : 0;
+    const int nb = (int)(maxCode >> shift) + 1;  // <= QT_BINS
+    for (int b = t; b <= nb; b += T) sh->binStart[b] = 0;
+    if (t == 0) sh->nBig = 0;
+    QT_BARRIER();
+    for (int r = t; r < n; r += T) QT_ATOMIC_ADD(&sh->binStart[(uint32_t)(tmp[r] >> 32) >> shift], 1);
+    QT_BARRIER();
+    qt_scan(sh->binStart, nb, sh);
+    for (int b = t; b < nb; b += T) sh->binCursor[b] = sh->binStart[b];
+    QT_BARRIER();
+    for (int r = t; r < n; r += T) {
+        const unsigned long long e = tmp[r];
+        const int pos = QT_ATOMIC_ADD(&sh->binCursor[(uint32_t)(e >> 32) >> shift], 1);
+        sorted[pos] = e;
+    }
+    QT_BARRIER();
+    // binCursor is free again: it now collects the buckets that need the workgroup
+    for (int b = t; b < nb; b += T) {
+        const int lo = sh->binStart[b], m = sh->binStart[b + 1] - lo;
+        if (m <= 1) continue;
+        if (m > QT_SMALL_BIN) {
+            sh->binCursor[QT_ATOMIC_ADD(&sh->nBig, 1)] = b;
+            continue;
+        }
+        unsigned long long* a = sorted + lo;
+        for (int i = 1; i < m; i++) {
+            const unsigned long long x = a[i];
+            int j = i - 1;
+            while (j >= 0 && a[j] > x) {
+                a[j + 1] = a[j];
+                j--;
+            }
+            a[j + 1] = x;
+        }
+    }
+    QT_BARRIER();
+    const int nBig = sh->nBig;
+    for (int k = 0; k < nBig; k++) {
+        const int b = sh->binCursor[k];
+        const int lo = sh->binStart[b];
+        qt_sort(sorted + lo, sh->binStart[b + 1] - lo);
+    }
+}
+
+// Winners of all `count` nodes of the final list: outRank[i] = rank of node i's
+// winner.  Nodes with few keys are handled by one thread each; a node that
+// still holds many keys (with the fork's n3 rule whole quadrants are never
+// divided) is scanned by the whole workgroup, reduced with one LDS atomic max
+// on (response << 32 | ~rank): largest response, then smallest rank.
+#define QT_SELECT_SERIAL 256
+QT_FN void qt_select_all(const unsigned long long* sorted, const unsigned long long* info, const OrbNode* list,
+                         int count, int* outRank, QtShared* sh) {
+    const int T = QT_NT, t = QT_TID;
+    if (t == 0) sh->nBig = 0;
+    QT_BARRIER();
+    for (int i = t; i < count; i += T) {
+        const OrbNode nd = list[i];
+        if (nd.hi - nd.lo > QT_SELECT_SERIAL) {
+            const int k = QT_ATOMIC_ADD(&sh->nBig, 1);
+            if (k < QT_BINS) {  // (more large nodes than list slots: the rest stay with their thread)
+                sh->binCursor[k] = i;
+                continue;
+            }
+        }
+        outRank[i] = qt_select(sorted, info, nd);
+    }
+    QT_BARRIER();
+    const int nBig = sh->nBig < QT_BINS ? sh->nBig : QT_BINS;
+    for (int k = 0; k < nBig; k++) {
+        const int i = sh->binCursor[k];
+        const OrbNode nd = list[i];
+        if (t == 0) sh->best64 = 0ull;
+        QT_BARRIER();
+        unsigned long long best = 0ull;
+        for (int p = nd.lo + t; p < nd.hi; p += T) {
+            const uint32_t r = (uint32_t)sorted[p];
+            const unsigned long long cand = ((info[r] >> 32) << 32) | (unsigned long long)(~r);
+            if (cand > best) best = cand;
+        }
+        if (best) QT_ATOMIC_MAX64(&sh->best64, best);
+        QT_BARRIER();
+        if (t == 0) outRank[i] = (int)(~(uint32_t)sh->best64);
+        QT_BARRIER();
+    }
 }

@@ -297,3 +297,22 @@ def test_brute_force_sharded_merge(hip, oracle):
         np.testing.assert_array_equal(d_s.cpu().numpy().view(np.uint16), so)
         for bf in shards:
             bf.close()
+
+
+def test_extract_4k_frame(hip, oracle):
+    """Config-4 shape: one 3840x2160 frame, 4000 features (about 130k FAST keys on level 0)."""
+    w, h, nf = 3840, 2160, 4000
+    img = synth_scene(w, h, frame_seed(4, 0))
+    c = _ctx(hip, "fork", nf, 8, w, h)
+    e = oracle.Extractor(nf, 1.2, 8, 20, 7, PRESETS["fork"])
+    kg, dg = c.extract(img)
+    ko, do = e.extract(img)
+    for l in (1, 7):
+        np.testing.assert_array_equal(c.pyramid_level(0, l), e.level(l), err_msg="pyramid level %d" % l)
+    xs, ys, sc = c.fast_keys(0, 0)
+    ref = e.level_keys(0, after_quadtree=False)
+    assert len(xs) == len(ref) and len(ref) > 50000
+    np.testing.assert_array_equal(xs, ref["x"].astype(np.int32))
+    assert_kps_equal(kg, ko, "4K frame")
+    np.testing.assert_array_equal(dg, do)
+    c.close()
