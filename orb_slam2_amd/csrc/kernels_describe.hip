@@ -17,7 +17,7 @@
 
 #define DESC_WAVES 4
 #define RAW_N 43
-#define RAW_P 44
+#define RAW_P 48   // 12 dwords: a window row starting at any byte alignment fits
 #define HB_P 38   // 37 columns of 16-bit horizontal sums
 #define BL_N 37
 #define BL_P 40
@@ -169,12 +169,29 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     uint16_t* hb = s_hb[wave];
     uint8_t* bl = s_bl[wave];
 
-    // 43x43 source window, reflected at the level's borders like the blur's BORDER_REFLECT_101.
-    for (int k = lane; k < RAW_N * RAW_N; k += 64) {
-        const int r = k / RAW_N, c = k - r * RAW_N;
-        const int sx = reflect101(px - 21 + c, L.w), sy = reflect101(py - 21 + r, L.h);
-        raw[r * RAW_P + c] = img[(int64_t)sy * pitch + sx];
+    // 43x43 source window.  Interior keypoints on 4-byte-aligned rows take whole dwords (12 per row,
+    // the window then starts `off` bytes into the LDS row); keypoints whose window leaves the level
+    // take bytes, reflected at the borders like the blur's BORDER_REFLECT_101.
+    const int wx0 = px - 21, wy0 = py - 21;
+    const int xa = wx0 & ~3;
+    const bool fastLoad = wx0 >= 0 && wy0 >= 0 && py + 21 < L.h && xa + RAW_P <= L.w && (pitch & 3) == 0 &&
+                          (((unsigned long long)img) & 3ull) == 0;
+    const int off = fastLoad ? (wx0 - xa) : 0;
+    if (fastLoad) {
+        const uint8_t* src = img + (int64_t)wy0 * pitch + xa;
+        uint32_t* raw32 = (uint32_t*)raw;
+        for (int k = lane; k < RAW_N * (RAW_P / 4); k += 64) {
+            const int r = k / (RAW_P / 4), d = k - r * (RAW_P / 4);
+            raw32[k] = *(const uint32_t*)(src + (int64_t)r * pitch + 4 * d);
+        }
+    } else {
+        for (int k = lane; k < RAW_N * RAW_N; k += 64) {
+            const int r = k / RAW_N, c = k - r * RAW_N;
+            const int sx = reflect101(wx0 + c, L.w), sy = reflect101(wy0 + r, L.h);
+            raw[r * RAW_P + c] = img[(int64_t)sy * pitch + sx];
+        }
     }
+    raw += off;  // window pixel (r, c) is raw[r * RAW_P + c] from here on
     wave_lds_sync();
 
     // Intensity centroid over the circular patch (rows v, half-width umax[|v|]).

@@ -120,15 +120,32 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(const OrbGeom* _
     uint8_t* tile = s_tile[wave];
     uint8_t* score = s_score[wave];
 
-    // (1) interior + halo -> LDS; zero the score tile.
+    // (1) interior + halo -> LDS; zero the score tile.  On 4-byte-aligned rows the tile is fetched as
+    // whole dwords (the tile then starts `off` bytes into each LDS row), otherwise byte by byte.
     const int tw = cw + 6, th = ch + 6;
-    const uint8_t* src = img + (int64_t)(Y0 - 3) * pitch + (X0 - 3);
-    for (int r = 0; r < th; r++) {
-        for (int x = lane; x < tw; x += 64) tile[r * TILE_PITCH + x] = src[(int64_t)r * pitch + x];
+    const int tx0 = X0 - 3;
+    const int xa = tx0 & ~3;
+    const int nd = ((tx0 - xa) + tw + 3) >> 2;  // dwords per tile row, <= 18
+    const bool fastLoad = (pitch & 3) == 0 && (((unsigned long long)img) & 3ull) == 0 &&
+                          xa + 4 * nd <= (level == 0 ? L.w : pitch);
+    const int off = fastLoad ? tx0 - xa : 0;
+    if (fastLoad) {
+        const uint8_t* src = img + (int64_t)(Y0 - 3) * pitch + xa;
+        const int total = th * nd;
+        for (int k = lane; k < total; k += 64) {
+            const int r = k / nd, d = k - r * nd;
+            *(uint32_t*)&tile[r * TILE_PITCH + 4 * d] = *(const uint32_t*)(src + (int64_t)r * pitch + 4 * d);
+        }
+    } else {
+        const uint8_t* src = img + (int64_t)(Y0 - 3) * pitch + tx0;
+        for (int r = 0; r < th; r++) {
+            for (int x = lane; x < tw; x += 64) tile[r * TILE_PITCH + x] = src[(int64_t)r * pitch + x];
+        }
     }
+    tile += off;  // tile pixel (r, c) is tile[r * TILE_PITCH + c] from here on
     {
         uint32_t* s32 = (uint32_t*)score;
-        for (int k = lane; k < SCORE_ROWS * SCORE_PITCH / 4; k += 64) s32[k] = 0u;
+        for (int k = lane; k < (ch + 2) * SCORE_PITCH / 4; k += 64) s32[k] = 0u;  // rows 0 .. ch+1 are read
     }
     wave_lds_sync();
 
