@@ -18,9 +18,10 @@
 #define DESC_WAVES 4
 #define RAW_N 43
 #define RAW_P 48   // 12 dwords: a window row starting at any byte alignment fits
-#define HB_P 38   // 37 columns of 16-bit horizontal sums
+#define HGROUPS 11 // 4-column groups of a 44-column aligned row
+#define HB_P 44    // 16-bit horizontal sums per row, at the aligned columns of the LDS row
 #define BL_N 37
-#define BL_P 40
+#define BL_P 44
 
 __constant__ signed char c_pattern[256 * 4] = {
 #include "orb_pattern.inc"
@@ -191,44 +192,86 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
             raw[r * RAW_P + c] = img[(int64_t)sy * pitch + sx];
         }
     }
-    raw += off;  // window pixel (r, c) is raw[r * RAW_P + c] from here on
     wave_lds_sync();
 
     // Intensity centroid over the circular patch (rows v, half-width umax[|v|]).
     const unsigned long long um = g->umaxPacked;
     int m10 = 0, m01 = 0;
-    for (int k = lane; k < 31 * 31; k += 64) {
-        const int r = k / 31, v = r - 15, u = k - r * 31 - 15;
-        const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-        const int lim = (int)((um >> (4 * av)) & 15ull);
-        if (au <= lim) {
-            const int val = raw[(21 + v) * RAW_P + 21 + u];
-            m10 += u * val;
-            m01 += v * val;
+    {
+        // rows v = -15..15, aligned column groups 1..9 (they cover u = -15..15 for every `off`)
+        const uint32_t* raw32 = (const uint32_t*)s_raw[wave];
+        for (int k = lane; k < 31 * 9; k += 64) {
+            const int r = k / 9, q = 1 + (k - r * 9);
+            const int v = r - 15, av = v < 0 ? -v : v;
+            const int lim = (int)((um >> (4 * av)) & 15ull);
+            const uint32_t w = raw32[(6 + r) * (RAW_P / 4) + q];
+            const int u0 = 4 * q - off - 21;
+            int rowSum = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int u = u0 + c, au = u < 0 ? -u : u;
+                const int val = (int)((w >> (8 * c)) & 255u);
+                if (au <= lim) {
+                    m10 += u * val;
+                    rowSum += val;
+                }
+            }
+            m01 += v * rowSum;
         }
     }
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // Blur of the 37x37 window: horizontal 8.8 sums, then vertical with one rounding.
+    // Blur of the 37x37 window the pattern can reach.  Both passes work on the aligned columns of the
+    // LDS rows, four at a time from whole dwords: horizontal 8.8 sums (16 bit), then vertical with one
+    // rounding.  Aligned columns outside [off + 3, off + 39] hold sums of bytes that are not part of
+    // the window; nothing reads them.
     const bool legacy = (g->quirks & ORB_Q_GAUSS_LEGACY) != 0;
-    const int k0 = 18, k1 = 34, k2 = legacy ? 49 : 48, k3 = legacy ? 55 : 56;
-    for (int k = lane; k < RAW_N * BL_N; k += 64) {
-        const int r = k / BL_N, c = k - r * BL_N;
-        const uint8_t* p = &raw[r * RAW_P + c];
-        hb[r * HB_P + c] = (uint16_t)(k0 * (p[0] + p[6]) + k1 * (p[1] + p[5]) + k2 * (p[2] + p[4]) + k3 * p[3]);
+    const uint32_t k0 = 18, k1 = 34, k2 = legacy ? 49 : 48, k3 = legacy ? 55 : 56;
+    const uint32_t* raw32 = (const uint32_t*)s_raw[wave];
+    uint32_t* hb32 = (uint32_t*)hb;
+    for (int k = lane; k < RAW_N * HGROUPS; k += 64) {
+        const int r = k / HGROUPS, q = k - r * HGROUPS;
+        const uint32_t* p = raw32 + r * (RAW_P / 4) + q;
+        const uint32_t A = p[q > 0 ? -1 : 0], B = p[0], C = p[1];
+        const uint32_t e0 = (A >> 8) & 255u, e1 = (A >> 16) & 255u, e2 = A >> 24;
+        const uint32_t e3 = B & 255u, e4 = (B >> 8) & 255u, e5 = (B >> 16) & 255u, e6 = B >> 24;
+        const uint32_t e7 = C & 255u, e8 = (C >> 8) & 255u, e9 = (C >> 16) & 255u;
+        const uint32_t o0 = k0 * (e0 + e6) + k1 * (e1 + e5) + k2 * (e2 + e4) + k3 * e3;
+        const uint32_t o1 = k0 * (e1 + e7) + k1 * (e2 + e6) + k2 * (e3 + e5) + k3 * e4;
+        const uint32_t o2 = k0 * (e2 + e8) + k1 * (e3 + e7) + k2 * (e4 + e6) + k3 * e5;
+        const uint32_t o3 = k0 * (e3 + e9) + k1 * (e4 + e8) + k2 * (e5 + e7) + k3 * e6;
+        uint2 o;
+        o.x = (o0 & 0xffffu) | (o1 << 16);
+        o.y = (o2 & 0xffffu) | (o3 << 16);
+        *(uint2*)(hb32 + r * (HB_P / 2) + 2 * q) = o;
     }
     wave_lds_sync();
-    for (int k = lane; k < BL_N * BL_N; k += 64) {
-        const int r = k / BL_N, c = k - r * BL_N;
-        const uint16_t* p = &hb[r * HB_P + c];
-        uint32_t v = (uint32_t)k0 * (p[0] + p[6 * HB_P]) + (uint32_t)k1 * (p[HB_P] + p[5 * HB_P]) +
-                     (uint32_t)k2 * (p[2 * HB_P] + p[4 * HB_P]) + (uint32_t)k3 * p[3 * HB_P];
-        v = (v + 32768u) >> 16;
-        bl[r * BL_P + c] = (uint8_t)(v > 255u ? 255u : v);
+    uint32_t* bl32 = (uint32_t*)bl;
+    for (int k = lane; k < BL_N * HGROUPS; k += 64) {
+        const int r = k / HGROUPS, q = k - r * HGROUPS;
+        const uint32_t* p = hb32 + r * (HB_P / 2) + 2 * q;
+        uint2 h[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) h[i] = *(const uint2*)(p + i * (HB_P / 2));
+        uint32_t packed = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            uint32_t s[7];
+#pragma unroll
+            for (int i = 0; i < 7; i++) {
+                const uint32_t w = (c & 2) ? h[i].y : h[i].x;
+                s[i] = (c & 1) ? (w >> 16) : (w & 0xffffu);
+            }
+            uint32_t v = k0 * (s[0] + s[6]) + k1 * (s[1] + s[5]) + k2 * (s[2] + s[4]) + k3 * s[3];
+            v = (v + 32768u) >> 16;
+            packed |= (v > 255u ? 255u : v) << (8 * c);
+        }
+        bl32[r * (BL_P / 4) + q] = packed;
     }
     wave_lds_sync();
+    bl += off + 3;  // blurred window pixel (r, c), c = 0..36, is bl[r * BL_P + c] from here on
 
     // rBRIEF: lane l of round r compares pair 64r + l; the ballot is descriptor bytes 8r..8r+7.
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
