@@ -82,6 +82,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(const OrbGeom* _
                                                                int* __restrict__ cellCount) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[FAST_WAVES][TILE_ROWS * TILE_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[FAST_WAVES][SCORE_ROWS * SCORE_PITCH];
+    __shared__ uint16_t s_cand[FAST_WAVES][128];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t cellGlobal = (int64_t)blockIdx.x * FAST_WAVES + wave;
     const int cellsPerFrame = g->cellsPerFrame;
@@ -149,17 +150,48 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(const OrbGeom* _
     }
     wave_lds_sync();
 
-    // (2) scores.  Cells up to 32 wide are walked two rows per step.
+    // (2) scores.  Cells up to 32 wide are walked two rows per step.  A pixel can only reach t* >= minTh
+    // if two adjacent compass points of its ring (any arc of 9 holds such a pair) both differ from the
+    // centre by more than minTh with the same sign; pixels passing that test are queued in a small LDS
+    // ring, in row-major order, and scored 64 at a time.  Everything else keeps the score 0.
     const int minTh = g->minTh, iniTh = g->iniTh;
     const int two = cw <= 32;
     const int ly = two ? (lane >> 5) : 0, lx = two ? (lane & 31) : lane;
     const int rowsPerStep = two ? 2 : 1;
     const int steps = (ch + rowsPerStep - 1) / rowsPerStep;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint16_t* cand = s_cand[wave];
+    int head = 0, tail = 0;  // wave-uniform ring positions, tail - head <= 127
     for (int p = 0; p < steps; p++) {
         const int y = p * rowsPerStep + ly;
+        bool pass = false;
         if (lx < cw && y < ch) {
-            const int t = fast_score(&tile[(y + 3) * TILE_PITCH + lx + 3]);
-            score[(y + 1) * SCORE_PITCH + lx + 1] = (uint8_t)(t >= minTh ? t : 0);
+            const uint8_t* c = &tile[(y + 3) * TILE_PITCH + lx + 3];
+            const int v = c[0];
+            const int dS = v - c[3 * TILE_PITCH], dE = v - c[3], dN = v - c[-3 * TILE_PITCH], dW = v - c[-3];
+            const bool bS = dS > minTh, bE = dE > minTh, bN = dN > minTh, bW = dW > minTh;
+            const bool kS = dS < -minTh, kE = dE < -minTh, kN = dN < -minTh, kW = dW < -minTh;
+            pass = ((bS | bN) & (bE | bW)) | ((kS | kN) & (kE | kW));
+        }
+        const unsigned long long m = __ballot(pass);
+        if (pass) cand[(tail + __popcll(m & below)) & 127] = (uint16_t)(lx | (y << 8));
+        tail += __popcll(m);
+        if (tail - head >= 64) {
+            wave_lds_sync();
+            const unsigned q = cand[(head + lane) & 127];
+            const int qx = q & 255, qy = q >> 8;
+            const int t = fast_score(&tile[(qy + 3) * TILE_PITCH + qx + 3]);
+            if (t >= minTh) score[(qy + 1) * SCORE_PITCH + qx + 1] = (uint8_t)t;
+            head += 64;
+        }
+    }
+    if (tail > head) {
+        wave_lds_sync();
+        if (lane < tail - head) {
+            const unsigned q = cand[(head + lane) & 127];
+            const int qx = q & 255, qy = q >> 8;
+            const int t = fast_score(&tile[(qy + 3) * TILE_PITCH + qx + 3]);
+            if (t >= minTh) score[(qy + 1) * SCORE_PITCH + qx + 1] = (uint8_t)t;
         }
     }
     wave_lds_sync();
@@ -191,7 +223,6 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(const OrbGeom* _
     const int cellCap = g->cellCap;
     uint32_t* out = cellKeys + cellGlobal * cellCap;
     int run = 0;
-    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (int p = 0; p < steps; p++) {
         const bool f = (keep >> p) & 1ull;
         const unsigned long long b = __ballot(f);

@@ -214,6 +214,28 @@ static void linear_taps(int ssize, int dsize, bool clampWeights, std::vector<Orb
     }
 }
 
+// Every tap of every resize tile must lie inside the source span the kernel stages for that tile.
+static int check_tile_spans(int ssize, int dsize, int tile, const OrbAreaTap* at, const OrbLinTap* lt) {
+    const double scale = orb_resize_scale(ssize, dsize);
+    for (int d = 0; d < dsize; d++) {
+        const int d0 = d / tile * tile, d1 = std::min(d0 + tile, dsize);
+        int s0, s1, lo, hi;
+        orb_resize_span(d0, d1, scale, ssize, &s0, &s1);
+        if (at) {
+            lo = hi = at[d].si[0];
+            for (int k = 1; k < ORB_MAX_TAPS && at[d].a[k] != 0.f; k++) hi = at[d].si[k];
+        } else {
+            lo = std::min(lt[d].s0, lt[d].s1);
+            hi = std::max(lt[d].s0, lt[d].s1);
+        }
+        if (lo < s0 || hi > s1) {
+            orb_set_error("resize %d -> %d: taps of destination index %d leave the staged source span", ssize, dsize, d);
+            return ORB_ERR_UNSUPPORTED;
+        }
+    }
+    return ORB_OK;
+}
+
 static inline int halfUp(int v) { return (v + 1) >> 1; }
 
 // Level sizes (src/ORBextractor.cc:917-918), FAST cell grid (:808-823), quadtree
@@ -315,6 +337,8 @@ static int compute_geom(orb_ctx* c, int w, int h) {
                 L.tabY = (int)at.size();
                 rc = area_taps(P.h, L.h, at);
                 if (rc) return rc;
+                if ((rc = check_tile_spans(P.w, L.w, ORB_RS_TW, &at[L.tabX], nullptr))) return rc;
+                if ((rc = check_tile_spans(P.h, L.h, ORB_RS_TH, &at[L.tabY], nullptr))) return rc;
             } else {
                 if (P.w == 2 * L.w && P.h == 2 * L.h) {
                     orb_set_error("exact 2:1 level ratio: cv::resize(INTER_LINEAR) switches to INTER_AREA there");
@@ -324,6 +348,9 @@ static int compute_geom(orb_ctx* c, int w, int h) {
                 linear_taps(P.w, L.w, true, lt);
                 L.tabY = (int)lt.size();
                 linear_taps(P.h, L.h, false, lt);
+                int rc;
+                if ((rc = check_tile_spans(P.w, L.w, ORB_RS_TW, nullptr, &lt[L.tabX]))) return rc;
+                if ((rc = check_tile_spans(P.h, L.h, ORB_RS_TH, nullptr, &lt[L.tabY]))) return rc;
             }
         }
     }
@@ -788,9 +815,13 @@ extern "C" int orb_resize(orb_ctx* c, const uint8_t* src, int sw, int sh, int ss
     if (area) {
         if ((rc = area_taps(sw, dw, at))) return rc;
         if ((rc = area_taps(sh, dh, at))) return rc;
+        if ((rc = check_tile_spans(sw, dw, ORB_RS_TW, &at[0], nullptr))) return rc;
+        if ((rc = check_tile_spans(sh, dh, ORB_RS_TH, &at[dw], nullptr))) return rc;
     } else {
         linear_taps(sw, dw, true, lt);
         linear_taps(sh, dh, false, lt);
+        if ((rc = check_tile_spans(sw, dw, ORB_RS_TW, nullptr, &lt[0]))) return rc;
+        if ((rc = check_tile_spans(sh, dh, ORB_RS_TH, nullptr, &lt[dw]))) return rc;
     }
     DevBuf dS, dD, dT;
     const size_t tabBytes = area ? at.size() * sizeof(OrbAreaTap) : lt.size() * sizeof(OrbLinTap);

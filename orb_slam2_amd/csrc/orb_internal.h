@@ -56,6 +56,43 @@ struct OrbLinTap {   // one destination index of the linear resize
     int s0, s1, a0, a1;
 };
 
+// Resize kernel tiling: a workgroup makes ORB_RS_TW x ORB_RS_TH destination pixels from a source
+// rectangle held in LDS.  orb_resize_span gives, per axis, a source index range that contains every
+// tap of destination indices [d0, d1): area taps lie in [floor(d0 * scale), floor(d1 * scale)],
+// linear taps in [floor(d0 * scale) - 1, floor(d1 * scale) + 2] once float rounding of the sample
+// position is allowed for.  The host checks the tap tables against it before the first launch.
+#define ORB_RS_TW 64
+#define ORB_RS_TH 16
+#define ORB_RS_TAP_BYTES ((ORB_RS_TW + ORB_RS_TH) * 32)
+#ifdef __HIPCC__
+#define ORB_HD __host__ __device__
+#else
+#define ORB_HD
+#endif
+static inline ORB_HD double orb_resize_scale(int ssize, int dsize) { return 1. / ((double)dsize / ssize); }
+static inline ORB_HD void orb_resize_span(int d0, int d1, double scale, int ssize, int* s0, int* s1) {
+    int lo = (int)(d0 * scale) - 1;  // operands are non-negative: truncation is floor
+    int hi = (int)(d1 * scale) + 2;
+    if (lo < 0) lo = 0;
+    if (hi > ssize - 1) hi = ssize - 1;
+    *s0 = lo;
+    *s1 = hi;
+}
+// Largest LDS extent any tile needs along one axis: bytes per row (dword-aligned start, whole dwords)
+// for the horizontal axis, rows for the vertical one.
+static inline void orb_resize_tile_extent(int ssize, int dsize, double scale, int tileSize, bool dwordAligned,
+                                          int* extent) {
+    int best = 0;
+    for (int d0 = 0; d0 < dsize; d0 += tileSize) {
+        const int d1 = d0 + tileSize < dsize ? d0 + tileSize : dsize;
+        int s0, s1;
+        orb_resize_span(d0, d1, scale, ssize, &s0, &s1);
+        const int e = dwordAligned ? 4 * ((s1 - (s0 & ~3) + 4) >> 2) : s1 - s0 + 1;
+        if (e > best) best = e;
+    }
+    *extent = best;
+}
+
 // Quadtree node as the kernel keeps it (keys of a node are a contiguous range of the code-sorted key array).
 struct OrbNode {
     int lo, hi;      // key range [lo, hi)
