@@ -1,105 +1,139 @@
 // DistributeOctTree for every (frame, level) of a batch: one workgroup each.
-// The algorithm itself is in quadtree_core.h; this file gathers the level's
-// FAST keys from the per-cell slots in the reference's order
-// (src/ORBextractor.cc:825-870: cell rows, cells, rows inside the cell), sorts
-// them by quadtree path and writes the winners in list order.
+// The algorithm itself is in quadtree_core.h.  This kernel first turns the
+// level's FAST keys (per-cell slots) into sort entries numbered in the
+// reference's order (src/ORBextractor.cc:825-870: cell rows, cells, rows inside
+// the cell), then sorts them by quadtree path, runs the distribution and
+// writes the winners in list order.
+//
+// Levels of everyday frame sizes keep the sorted keys and all node scratch in
+// LDS; larger ones (a 4K level holds ~1e5 keys) use the global-memory buffers
+// of the same layout.
 #include <hip/hip_runtime.h>
 
 #include "quadtree_core.h"
 
 #define QT_MAX_THREADS 1024
+#define QT_LDS_KEYS 4096
+
+// Sort, distribute, select and emit one level.  Inlined once per memory placement so that the
+// compiler sees which address space `sorted` and the node scratch live in.
+static __device__ __forceinline__ int qt_level(const OrbGeom* g, const OrbLevel& L, const unsigned long long* tmp,
+                                               unsigned long long* sorted, const QtWork& w0, int n,
+                                               const uint32_t* __restrict__ levelCellKeys, uint32_t* __restrict__ selXY,
+                                               int* __restrict__ selScore, int* __restrict__ error, QtShared* sh) {
+    const int t = threadIdx.x, T = (int)blockDim.x;
+    qt_sort_keys(tmp, sorted, n, L.nIni, sh);
+    __syncthreads();  // the bucket arrays may now be reused as node scratch
+    QtWork w = w0;
+    w.sorted = sorted;
+    OrbNode* list = nullptr;
+    int count = 0;
+    qt_distribute(w, n, L.nIni, L.quota, (g->quirks & ORB_Q_DIVIDE_N3) ? 1 : 0, sh, &list, &count);
+    if (sh->err && t == 0) atomicOr(error, sh->err == 2 ? 8 : 16);
+    if (count > L.outCap) {  // cannot happen (quota + 2 bound); fail loudly, never truncate silently
+        if (t == 0) atomicOr(error, 32);
+        count = L.outCap;
+    }
+    qt_select_all(sorted, list, count, w.scanA, sh);
+    const int cellCap = g->cellCap;
+    for (int i = t; i < count; i += T) {
+        const int rank = w.scanA[i];
+        const uint32_t key = levelCellKeys[rank];  // rank = cell * cellCap + position inside the cell
+        const int cell = rank / cellCap;
+        const int ci = cell / L.nCols, cj = cell - ci * L.nCols;
+        const int x = 3 + cj * L.wCell + (int)(key & 0xff);  // relative to the 16-pixel border, src/ORBextractor.cc:864-865
+        const int y = 3 + ci * L.hCell + (int)((key >> 8) & 0xff);
+        selXY[i] = (uint32_t)x | ((uint32_t)y << 16);
+        selScore[i] = (int)(key >> 16);
+    }
+    return count;
+}
 
 __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __restrict__ g, int nframes,
                                                         const uint32_t* __restrict__ cellKeys,
-                                                        const int* __restrict__ cellCount, int* __restrict__ cellOff,
+                                                        const int* __restrict__ cellCount,
                                                         unsigned long long* __restrict__ sortBuf,
-                                                        unsigned long long* __restrict__ keyInfo,
                                                         OrbNode* __restrict__ nodes, int* __restrict__ ints,
                                                         uint32_t* __restrict__ selXY, int* __restrict__ selScore,
                                                         int* __restrict__ levelCount, int* __restrict__ levelKeys,
                                                         int* __restrict__ error) {
     __shared__ QtShared sh;
+    __shared__ unsigned long long s_keys[QT_LDS_KEYS];
     const int nlevels = g->nlevels;
     const int frame = blockIdx.x / nlevels, level = blockIdx.x - frame * nlevels;
     const OrbLevel& L = g->lv[level];
     const int t = threadIdx.x, T = (int)blockDim.x;
-    const int nCells = L.nCols * L.nRows;
-    const int64_t cell0 = (int64_t)frame * g->cellsPerFrame + L.cellBase;
-    const int* cc = cellCount + cell0;
-    int* off = cellOff + (int64_t)frame * (g->cellsPerFrame + nlevels) + L.cellBase + level;  // nCells + 1 entries
-    unsigned long long* sorted = sortBuf + ((int64_t)frame * g->keysPerFrame + L.keyBase) * 2;
-    unsigned long long* tmp = sorted + L.keyCap;
-    unsigned long long* info = keyInfo + (int64_t)frame * g->keysPerFrame + L.keyBase;
+    unsigned long long* sortedG = sortBuf + ((int64_t)frame * g->keysPerFrame + L.keyBase) * 2;
+    unsigned long long* tmp = sortedG + L.keyCap;
+    const uint32_t* lck = cellKeys + ((int64_t)frame * g->cellsPerFrame + L.cellBase) * g->cellCap;
 
-    for (int c = t; c < nCells; c += T) off[c] = cc[c];
-    __syncthreads();
-    qt_scan(off, nCells, &sh);
-    const int n = off[nCells];
+    // Gather: cells are taken in chunks whose key offsets fit the LDS bucket array; every thread then
+    // owns keys (not cells), finds each key's cell by binary search over the chunk's offsets and
+    // writes its sort entry.  All loads of a thread are independent of each other.
+    const int* cc = cellCount + (int64_t)frame * g->cellsPerFrame + L.cellBase;
+    const int nCells = L.nCols * L.nRows, cellCap = g->cellCap;
+    const int height = L.maxBorderY - ORB_BORDER;
+    int n = 0;
+    for (int c0 = 0; c0 < nCells; c0 += QT_BINS) {
+        const int m = nCells - c0 < QT_BINS ? nCells - c0 : QT_BINS;
+        int* off = sh.binStart;
+        for (int c = t; c < m; c += T) off[c] = cc[c0 + c];
+        __syncthreads();
+        qt_scan(off, m, &sh);
+        const int chunk = off[m];
+        for (int r = t; r < chunk; r += T) {
+            int lo = 0, hi = m;  // largest c with off[c] <= r
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (off[mid] <= r) lo = mid; else hi = mid;
+            }
+            const int k = r - off[lo], cell = c0 + lo;
+            const uint32_t key = lck[(int64_t)cell * cellCap + k];
+            const int ci = cell / L.nCols, cj = cell - ci * L.nCols;
+            const int x = 3 + cj * L.wCell + (int)(key & 0xff);  // relative to the 16-pixel border, as :864-865
+            const int y = 3 + ci * L.hCell + (int)((key >> 8) & 0xff);
+            if (n + r < L.keyCap)
+                tmp[n + r] = qt_entry(qt_code(x, y, L.nIni, L.hX, height), (uint32_t)(cell * cellCap + k), key >> 16);
+        }
+        n += chunk;
+        __syncthreads();
+    }
+    if (t == 0) levelKeys[frame * nlevels + level] = n;
     if (n > L.keyCap) {  // cannot happen: keyCap is the 2x2-block bound summed over the cells
         if (t == 0) {
             atomicOr(error, 4);
             levelCount[frame * nlevels + level] = 0;
-            levelKeys[frame * nlevels + level] = n;
         }
         return;
     }
-    const int cellCap = g->cellCap;
-    const int height = L.maxBorderY - ORB_BORDER;
-    for (int c = t; c < nCells; c += T) {
-        const int cnt = cc[c], base = off[c];
-        const int ci = c / L.nCols, cj = c - ci * L.nCols;
-        const uint32_t* slot = cellKeys + (cell0 + c) * cellCap;
-        for (int k = 0; k < cnt; k++) {
-            const uint32_t key = slot[k];
-            const int x = 3 + cj * L.wCell + (int)(key & 0xff);  // relative to the 16-pixel border, as :864-865
-            const int y = 3 + ci * L.hCell + (int)((key >> 8) & 0xff);
-            const int r = base + k;
-            tmp[r] = ((unsigned long long)qt_code(x, y, L.nIni, L.hX, height) << 32) | (unsigned)r;
-            info[r] = (unsigned long long)(unsigned)x | ((unsigned long long)(unsigned)y << 16) |
-                      ((unsigned long long)(key >> 16) << 32);
-        }
-    }
-    __syncthreads();
     int count = 0;
     if (n > 0) {
-        qt_sort_keys(tmp, sorted, n, L.nIni, &sh);
-        QtWork w;
-        w.sorted = sorted;
-        w.nodeCap = L.nodeCap;
-        OrbNode* nb = nodes + ((int64_t)frame * g->nodesPerFrame + L.nodeBase) * 2;
-        w.listA = nb;
-        w.listB = nb + L.nodeCap;
-        int* p = ints + ((int64_t)frame * g->nodesPerFrame + L.nodeBase) * 9 + (int64_t)(frame * nlevels + level) * 4;
-        w.rec = p;
-        p += L.nodeCap;
-        w.recSorted = p;
-        p += L.nodeCap;
-        w.bounds = p;
-        p += 4 * L.nodeCap;
-        w.scanA = p;
-        p += L.nodeCap + 1;
-        w.scanB = p;
-        p += L.nodeCap + 1;
-        w.scanC = p;
-        OrbNode* list = nullptr;
-        qt_distribute(w, n, L.nIni, L.quota, (g->quirks & ORB_Q_DIVIDE_N3) ? 1 : 0, &sh, &list, &count);
-        if (sh.err && t == 0) atomicOr(error, sh.err == 2 ? 8 : 16);
-        if (count > L.outCap) {  // cannot happen (quota + 2 bound); fail loudly, never truncate silently
-            if (t == 0) atomicOr(error, 32);
-            count = L.outCap;
-        }
         const int64_t ob = (int64_t)frame * g->outCapFrame + L.outBase;
-        qt_select_all(sorted, info, list, count, w.scanA, &sh);
-        for (int i = t; i < count; i += T) {
-            const unsigned long long ki = info[w.scanA[i]];
-            selXY[ob + i] = (uint32_t)ki;
-            selScore[ob + i] = (int)(ki >> 32);
+        QtWork w;
+        if (n <= QT_LDS_KEYS && QT_NODE_INTS(L.nodeCap) <= QT_POOL_INTS) {
+            qt_work_from_pool(&w, sh.binStart, L.nodeCap);
+            count = qt_level(g, L, tmp, s_keys, w, n, lck, selXY + ob, selScore + ob, error, &sh);
+        } else {
+            OrbNode* nb = nodes + ((int64_t)frame * g->nodesPerFrame + L.nodeBase) * 2;
+            int* p = ints + ((int64_t)frame * g->nodesPerFrame + L.nodeBase) * 9 + (int64_t)(frame * nlevels + level) * 4;
+            w.nodeCap = L.nodeCap;
+            w.listA = nb;
+            w.listB = nb + L.nodeCap;
+            w.rec = p;
+            p += L.nodeCap;
+            w.recSorted = p;
+            p += L.nodeCap;
+            w.bounds = p;
+            p += 4 * L.nodeCap;
+            w.scanA = p;
+            p += L.nodeCap + 1;
+            w.scanB = p;
+            p += L.nodeCap + 1;
+            w.scanC = p;
+            count = qt_level(g, L, tmp, sortedG, w, n, lck, selXY + ob, selScore + ob, error, &sh);
         }
     }
-    if (t == 0) {
-        levelCount[frame * nlevels + level] = count;
-        levelKeys[frame * nlevels + level] = n;
-    }
+    if (t == 0) levelCount[frame * nlevels + level] = count;
 }
 
 int orb_launch_quadtree(const OrbBatch& b) {
@@ -107,8 +141,8 @@ int orb_launch_quadtree(const OrbBatch& b) {
     // large levels (4K frames hand ~1e5 keys to the quadtree) get a full 1024-thread workgroup
     const int threads = g.lv[0].keyCap > 400000 ? 1024 : 256;
     hipLaunchKernelGGL(k_quadtree, dim3(b.nframes * g.nlevels), dim3(threads), 0, (hipStream_t)b.stream, b.d_geom,
-                       b.nframes, b.d_cellKeys, b.d_cellCount, b.d_cellOff, b.d_sort, b.d_keyInfo, b.d_nodes, b.d_ints,
-                       b.d_selXY, b.d_selScore, b.d_levelCount, b.d_levelKeys, b.d_error);
+                       b.nframes, b.d_cellKeys, b.d_cellCount, b.d_sort, b.d_nodes, b.d_ints, b.d_selXY, b.d_selScore, b.d_levelCount,
+                       b.d_levelKeys, b.d_error);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         orb_set_error("quadtree launch failed: %s", hipGetErrorString(e));

@@ -78,7 +78,7 @@ struct orb_ctx {
     std::vector<OrbAreaTap> areaTaps;
     std::vector<OrbLinTap> linTaps;
     hipStream_t stream = nullptr;
-    DevBuf dGeom, dAreaTaps, dLinTaps, dInput, dPyr, dCellKeys, dCellCount, dCellOff, dSort, dInfo, dNodes, dInts,
+    DevBuf dGeom, dAreaTaps, dLinTaps, dInput, dPyr, dCellKeys, dCellCount, dSort, dNodes, dInts,
         dSelXY, dSelScore, dLevelCount, dLevelKeys, dError, dKps, dDesc, dNOut, dTmpA, dTmpB;
     int lastFrames = 0;
     int inputStride = 0;
@@ -360,6 +360,12 @@ static int compute_geom(orb_ctx* c, int w, int h) {
                       (1 << (ORB_CODE_DEPTH - 1)) + 2 * ORB_BORDER);
         return ORB_ERR_UNSUPPORTED;
     }
+    for (int l = 0; l < g.nlevels; l++) {
+        if ((int64_t)g.lv[l].nCols * g.lv[l].nRows * cellCap > (int64_t)1 << 24) {
+            orb_set_error("frame too large: level %d needs more than 2^24 key ranks", l);
+            return ORB_ERR_UNSUPPORTED;
+        }
+    }
     g.cellsPerFrame = cellBase;
     g.cellCap = cellCap;
     g.outCapFrame = outBase;
@@ -410,9 +416,7 @@ static int ensure_buffers(orb_ctx* c, int n) {
     if ((rc = c->dPyr.ensure((size_t)std::max<int64_t>(pyr, 64)))) return rc;
     if ((rc = c->dCellKeys.ensure((size_t)n * g.cellsPerFrame * g.cellCap * 4))) return rc;
     if ((rc = c->dCellCount.ensure((size_t)n * g.cellsPerFrame * 4))) return rc;
-    if ((rc = c->dCellOff.ensure((size_t)n * (g.cellsPerFrame + g.nlevels) * 4))) return rc;
     if ((rc = c->dSort.ensure((size_t)n * g.keysPerFrame * 16 + 16))) return rc;
-    if ((rc = c->dInfo.ensure((size_t)n * g.keysPerFrame * 8 + 8))) return rc;
     if ((rc = c->dNodes.ensure((size_t)n * g.nodesPerFrame * 2 * sizeof(OrbNode)))) return rc;
     if ((rc = c->dInts.ensure(((size_t)n * g.nodesPerFrame * 9 + (size_t)n * g.nlevels * 4) * 4))) return rc;
     if ((rc = c->dSelXY.ensure((size_t)n * g.outCapFrame * 4))) return rc;
@@ -481,7 +485,7 @@ extern "C" void orb_destroy(orb_ctx* c) {
     (void)hipSetDevice(c->prm.device);
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c->dGeom, &c->dAreaTaps, &c->dLinTaps, &c->dInput, &c->dPyr, &c->dCellKeys, &c->dCellCount,
-                      &c->dCellOff, &c->dSort, &c->dInfo, &c->dNodes, &c->dInts, &c->dSelXY, &c->dSelScore,
+                      &c->dSort, &c->dNodes, &c->dInts, &c->dSelXY, &c->dSelScore,
                       &c->dLevelCount, &c->dLevelKeys, &c->dError, &c->dKps, &c->dDesc, &c->dNOut, &c->dTmpA,
                       &c->dTmpB};
     for (DevBuf* b : bufs) b->release();
@@ -550,9 +554,7 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
     b.d_linTaps = (const OrbLinTap*)c->dLinTaps.p;
     b.d_cellKeys = (uint32_t*)c->dCellKeys.p;
     b.d_cellCount = (int*)c->dCellCount.p;
-    b.d_cellOff = (int*)c->dCellOff.p;
     b.d_sort = (unsigned long long*)c->dSort.p;
-    b.d_keyInfo = (unsigned long long*)c->dInfo.p;
     b.d_nodes = (OrbNode*)c->dNodes.p;
     b.d_ints = (int*)c->dInts.p;
     b.d_selXY = (uint32_t*)c->dSelXY.p;

@@ -113,15 +113,13 @@ struct OrbBatch {  // everything one extraction launch sequence needs
     const OrbLinTap* d_linTaps;
     uint32_t* d_cellKeys;       // [frame][cell][cellCap]: x | y << 8 | score << 16, cell-interior coordinates
     int* d_cellCount;           // [frame][cell]
-    int* d_cellOff;             // [frame][cellsPerFrame + nlevels] scan scratch
-    unsigned long long* d_sort; // [frame][keysPerFrame]: quadtree path << 32 | rank
-    unsigned long long* d_keyInfo;  // [frame][keysPerFrame]: x | y << 16 | score << 32 by rank
+    unsigned long long* d_sort; // [frame][2 * keysPerFrame]: per level keyCap sorted entries, then keyCap unsorted ones
     OrbNode* d_nodes;           // [frame][nodesPerFrame * 2]
     int* d_ints;                // [frame][nodesPerFrame * 9 + nlevels * 4]
     uint32_t* d_selXY;          // [frame][outCapFrame]: x | y << 16 (relative to the 16-pixel border)
     int* d_selScore;            // [frame][outCapFrame]
     int* d_levelCount;          // [frame][nlevels] keypoints kept per level
-    int* d_levelKeys;           // [frame][nlevels] keys handed to the quadtree
+    int* d_levelKeys;           // [frame][nlevels] keys handed to the quadtree (counted by the FAST kernel)
     int* d_error;               // flag word, OR of limit bits
     orb_keypoint* d_kps;
     uint8_t* d_desc;

@@ -28,7 +28,7 @@
 #define QT_NT 1
 #define QT_FDIV(a, b) ((a) / (b))
 #define QT_ATOMIC_ADD(p, v) qt_host_fetch_add((p), (v))
-#define QT_ATOMIC_MAX64(p, v) (*(p) = (*(p) > (v)) ? *(p) : (v))
+#define QT_ATOMIC_MAX32(p, v) (*(p) = (*(p) > (v)) ? *(p) : (v))
 static inline int qt_host_fetch_add(int* p, int v) {
     const int o = *p;
     *p = o + v;
@@ -41,7 +41,7 @@ static inline int qt_host_fetch_add(int* p, int v) {
 #define QT_NT ((int)blockDim.x)
 #define QT_FDIV(a, b) __fdiv_rn((a), (b))
 #define QT_ATOMIC_ADD(p, v) atomicAdd((p), (v))
-#define QT_ATOMIC_MAX64(p, v) atomicMax((p), (v))
+#define QT_ATOMIC_MAX32(p, v) atomicMax((p), (v))
 #endif
 
 #define QT_NOMORE 0x100
@@ -50,18 +50,38 @@ static inline int qt_host_fetch_add(int* p, int v) {
 #define QT_BINS 4096      // buckets of the key sort
 #define QT_SMALL_BIN 40   // buckets up to this size are sorted by one thread
 
+#define QT_BIG_LIST 128   // nodes handed to the whole workgroup by the winner selection
+#define QT_POOL_INTS (2 * QT_BINS + 1)
+#define QT_NODE_INTS(cap) (17 * (cap) + 3)  // ints of node scratch one (frame, level) needs, see qt_work_from_pool
+
+// Sort entry: quadtree path << 32 | rank << 8 | response.  The rank (24 bits) numbers the level's keys
+// in the reference's order (cell rows, cells, rows inside the cell, with gaps); entries are unique, and
+// ascending order of the whole word is (path, rank) order.
+#define QT_RANK_BITS 24
+QT_FN unsigned long long qt_entry(uint32_t code, uint32_t rank, uint32_t score) {
+    return ((unsigned long long)code << 32) | ((unsigned long long)rank << 8) | (unsigned long long)(score & 255u);
+}
+QT_FN uint32_t qt_entry_rank(unsigned long long e) { return (uint32_t)(e >> 8) & 0xffffffu; }
+// Winner order (src/ORBextractor.cc:777-793): largest response, earliest key on ties.
+QT_FN uint32_t qt_entry_prio(unsigned long long e) {
+    return (((uint32_t)e & 255u) << 24) | (~(uint32_t)(e >> 8) & 0xffffffu);
+}
+
 struct QtShared {
-    int part[1024];  // per-thread partial sums of the block scan
+    int part[64];    // per-wavefront partial sums of the block scan
+    // Key-sort buckets; once the keys are sorted the same words serve as node scratch (QT_POOL_INTS ints
+    // from binStart on) when a level's node pool fits.
     int binStart[QT_BINS + 1];
     int binCursor[QT_BINS];
+    int bigList[QT_BIG_LIST];
     int nBig;
-    unsigned long long best64;
+    unsigned best32;
     int total;
     int nL, prevSize, nToExpand, seqCounter, nRec, finish, fine, stop, err;
 };
 
-struct QtWork {  // scratch of one (frame, level), all in global memory
-    unsigned long long* sorted;  // n entries: code << 32 | rank, ascending
+struct QtWork {  // scratch of one (frame, level): LDS when it fits, global memory otherwise
+    const unsigned long long* sorted;  // n entries, ascending
     OrbNode* listA;              // nodeCap
     OrbNode* listB;              // nodeCap
     int* rec;                    // nodeCap: positions (in the current list) of recorded nodes
@@ -72,6 +92,26 @@ struct QtWork {  // scratch of one (frame, level), all in global memory
     int* scanC;                  // nodeCap + 1
     int nodeCap;
 };
+
+// Lays the node scratch out in `pool` (QT_NODE_INTS(nodeCap) ints).
+QT_FN void qt_work_from_pool(QtWork* w, int* pool, int nodeCap) {
+    w->nodeCap = nodeCap;
+    w->listA = (OrbNode*)pool;
+    pool += 4 * nodeCap;
+    w->listB = (OrbNode*)pool;
+    pool += 4 * nodeCap;
+    w->rec = pool;
+    pool += nodeCap;
+    w->recSorted = pool;
+    pool += nodeCap;
+    w->bounds = pool;
+    pool += 4 * nodeCap;
+    w->scanA = pool;
+    pool += nodeCap + 1;
+    w->scanB = pool;
+    pool += nodeCap + 1;
+    w->scanC = pool;
+}
 
 // Quadtree path of a key: 4 bits initial node, then ORB_CODE_DEPTH two-bit
 // quadrant digits (0 = n1 left/top, 1 = n2 right/top, 2 = n3 left/bottom,
@@ -412,23 +452,22 @@ QT_FN void qt_sort(unsigned long long* a, int n) {
     }
 }
 
-// Winner of a node: largest response, earliest key (smallest rank) on ties
-// (src/ORBextractor.cc:777-793).  info[rank] = x | y << 16 | score << 32.
-QT_FN int qt_select(const unsigned long long* sorted, const unsigned long long* info, const OrbNode& nd) {
-    int bestRank = (int)(uint32_t)sorted[nd.lo];
-    int bestScore = (int)(info[bestRank] >> 32);
+// Winner of a node: rank of the entry with the largest priority.
+QT_FN int qt_select(const unsigned long long* sorted, const OrbNode& nd) {
+    unsigned long long best = sorted[nd.lo];
+    uint32_t bestPrio = qt_entry_prio(best);
     for (int i = nd.lo + 1; i < nd.hi; i++) {
-        const int r = (int)(uint32_t)sorted[i];
-        const int sc = (int)(info[r] >> 32);
-        if (sc > bestScore || (sc == bestScore && r < bestRank)) {
-            bestScore = sc;
-            bestRank = r;
+        const unsigned long long e = sorted[i];
+        const uint32_t pr = qt_entry_prio(e);
+        if (pr > bestPrio) {
+            bestPrio = pr;
+            best = e;
         }
     }
-    return bestRank;
+    return (int)qt_entry_rank(best);
 }
 
-// Sorts the n (code << 32 | rank) entries of `tmp` into `sorted`, ascending.
+// Sorts the n entries of `tmp` into `sorted`, ascending.
 // Entries are first bucketed by the leading bits of the quadtree path (one
 // histogram + one scatter over all keys, LDS counters), which already puts
 // every bucket into its final slice; buckets are then ordered internally, small
@@ -486,11 +525,11 @@ QT_FN void qt_sort_keys(const unsigned long long* tmp, unsigned long long* sorte
 // Winners of all `count` nodes of the final list: outRank[i] = rank of node i's
 // winner.  Nodes with few keys are handled by one thread each; a node that
 // still holds many keys (with the fork's n3 rule whole quadrants are never
-// divided) is scanned by the whole workgroup, reduced with one LDS atomic max
-// on (response << 32 | ~rank): largest response, then smallest rank.
-#define QT_SELECT_SERIAL 256
-QT_FN void qt_select_all(const unsigned long long* sorted, const unsigned long long* info, const OrbNode* list,
-                         int count, int* outRank, QtShared* sh) {
+// divided) is scanned by the whole workgroup and reduced with one LDS atomic
+// max on the priority word; the rank is the complement of its low 24 bits.
+#define QT_SELECT_SERIAL 64
+QT_FN void qt_select_all(const unsigned long long* sorted, const OrbNode* list, int count, int* outRank,
+                         QtShared* sh) {
     const int T = QT_NT, t = QT_TID;
     if (t == 0) sh->nBig = 0;
     QT_BARRIER();
@@ -498,29 +537,28 @@ QT_FN void qt_select_all(const unsigned long long* sorted, const unsigned long l
         const OrbNode nd = list[i];
         if (nd.hi - nd.lo > QT_SELECT_SERIAL) {
             const int k = QT_ATOMIC_ADD(&sh->nBig, 1);
-            if (k < QT_BINS) {  // (more large nodes than list slots: the rest stay with their thread)
-                sh->binCursor[k] = i;
+            if (k < QT_BIG_LIST) {  // (more large nodes than list slots: the rest stay with their thread)
+                sh->bigList[k] = i;
                 continue;
             }
         }
-        outRank[i] = qt_select(sorted, info, nd);
+        outRank[i] = qt_select(sorted, nd);
     }
     QT_BARRIER();
-    const int nBig = sh->nBig < QT_BINS ? sh->nBig : QT_BINS;
+    const int nBig = sh->nBig < QT_BIG_LIST ? sh->nBig : QT_BIG_LIST;
     for (int k = 0; k < nBig; k++) {
-        const int i = sh->binCursor[k];
+        const int i = sh->bigList[k];
         const OrbNode nd = list[i];
-        if (t == 0) sh->best64 = 0ull;
+        if (t == 0) sh->best32 = 0u;
         QT_BARRIER();
-        unsigned long long best = 0ull;
+        uint32_t best = 0u;
         for (int p = nd.lo + t; p < nd.hi; p += T) {
-            const uint32_t r = (uint32_t)sorted[p];
-            const unsigned long long cand = ((info[r] >> 32) << 32) | (unsigned long long)(~r);
-            if (cand > best) best = cand;
+            const uint32_t pr = qt_entry_prio(sorted[p]);
+            if (pr > best) best = pr;
         }
-        if (best) QT_ATOMIC_MAX64(&sh->best64, best);
+        if (best) QT_ATOMIC_MAX32(&sh->best32, best);
         QT_BARRIER();
-        if (t == 0) outRank[i] = (int)(~(uint32_t)sh->best64);
+        if (t == 0) outRank[i] = (int)(~sh->best32 & 0xffffffu);
         QT_BARRIER();
     }
 }
