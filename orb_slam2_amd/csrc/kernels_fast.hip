@@ -25,6 +25,7 @@
 #define TILE_ROWS 66                                    // >= 59 + 6
 #define SCORE_PITCH 64                                  // >= 59 + 2
 #define SCORE_ROWS 62                                   // >= 59 + 2
+#define CORN_CAP 256                                    // corners listed per cell for the suppression pass
 
 static __device__ __forceinline__ void wave_lds_sync() {
     // LDS operations of one wavefront execute in issue order; this only stops the
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(const OrbGeom* _
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[FAST_WAVES][TILE_ROWS * TILE_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[FAST_WAVES][SCORE_ROWS * SCORE_PITCH];
     __shared__ uint16_t s_cand[FAST_WAVES][128];
+    __shared__ uint16_t s_corn[FAST_WAVES][CORN_CAP];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t cellGlobal = (int64_t)blockIdx.x * FAST_WAVES + wave;
     const int cellsPerFrame = g->cellsPerFrame;
@@ -161,56 +163,80 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(const OrbGeom* _
     const int steps = (ch + rowsPerStep - 1) / rowsPerStep;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint16_t* cand = s_cand[wave];
+    uint16_t* corn = s_corn[wave];
     int head = 0, tail = 0;  // wave-uniform ring positions, tail - head <= 127
-    for (int p = 0; p < steps; p++) {
-        const int y = p * rowsPerStep + ly;
-        bool pass = false;
-        if (lx < cw && y < ch) {
-            const uint8_t* c = &tile[(y + 3) * TILE_PITCH + lx + 3];
-            const int v = c[0];
-            const int dS = v - c[3 * TILE_PITCH], dE = v - c[3], dN = v - c[-3 * TILE_PITCH], dW = v - c[-3];
-            const bool bS = dS > minTh, bE = dE > minTh, bN = dN > minTh, bW = dW > minTh;
-            const bool kS = dS < -minTh, kE = dE < -minTh, kN = dN < -minTh, kW = dW < -minTh;
-            pass = ((bS | bN) & (bE | bW)) | ((kS | kN) & (kE | kW));
-        }
-        const unsigned long long m = __ballot(pass);
-        if (pass) cand[(tail + __popcll(m & below)) & 127] = (uint16_t)(lx | (y << 8));
-        tail += __popcll(m);
-        if (tail - head >= 64) {
-            wave_lds_sync();
-            const unsigned q = cand[(head + lane) & 127];
-            const int qx = q & 255, qy = q >> 8;
-            const int t = fast_score(&tile[(qy + 3) * TILE_PITCH + qx + 3]);
-            if (t >= minTh) score[(qy + 1) * SCORE_PITCH + qx + 1] = (uint8_t)t;
-            head += 64;
-        }
-    }
-    if (tail > head) {
+    int nCorn = 0;           // corners found (t* >= minTh); the first CORN_CAP are listed, in row-major order
+    // scores 64 queued candidates (lanes below `count`), marks corners in the score tile and the list
+    auto score_chunk = [&](int count) {
         wave_lds_sync();
-        if (lane < tail - head) {
-            const unsigned q = cand[(head + lane) & 127];
+        bool corner = false;
+        unsigned q = 0;
+        int t = 0;
+        if (lane < count) {
+            q = cand[(head + lane) & 127];
             const int qx = q & 255, qy = q >> 8;
-            const int t = fast_score(&tile[(qy + 3) * TILE_PITCH + qx + 3]);
-            if (t >= minTh) score[(qy + 1) * SCORE_PITCH + qx + 1] = (uint8_t)t;
+            t = fast_score(&tile[(qy + 3) * TILE_PITCH + qx + 3]);
+            corner = t >= minTh;
+            if (corner) score[(qy + 1) * SCORE_PITCH + qx + 1] = (uint8_t)t;
+        }
+        const unsigned long long m = __ballot(corner);
+        if (corner) {
+            const int pos = nCorn + __popcll(m & below);
+            if (pos < CORN_CAP) corn[pos] = (uint16_t)q;
+        }
+        nCorn += __popcll(m);
+        head += count;
+    };
+    {
+        const bool xin = lx < cw;
+        const uint8_t* c = &tile[(ly + 3) * TILE_PITCH + lx + 3];
+        int y = ly;
+        for (int p = 0; p < steps; p++, y += rowsPerStep, c += rowsPerStep * TILE_PITCH) {
+            bool pass = false;
+            if (xin && y < ch) {
+                const int v = c[0];
+                const int dS = v - c[3 * TILE_PITCH], dE = v - c[3], dN = v - c[-3 * TILE_PITCH], dW = v - c[-3];
+                const int hiV = min(max(dS, dN), max(dE, dW));  // > minTh: an adjacent compass pair is darker
+                const int loV = max(min(dS, dN), min(dE, dW));  // < -minTh: an adjacent compass pair is brighter
+                pass = hiV > minTh || loV < -minTh;
+            }
+            const unsigned long long m = __ballot(pass);
+            if (pass) cand[(tail + __popcll(m & below)) & 127] = (uint16_t)(lx | (y << 8));
+            tail += __popcll(m);
+            if (tail - head >= 64) score_chunk(64);
         }
     }
+    if (tail > head) score_chunk(tail - head);
     wave_lds_sync();
 
-    // (3) local maxima, counted for both thresholds; per-lane bit p remembers step p.
+    // (3) local maxima, counted for both thresholds, then the kept keys in row-major order.  With few
+    // corners the listed ones are visited (bit k of a lane's mask remembers chunk k); a cell with more
+    // corners than the list holds walks all its pixels instead (bit p remembers step p).
+    const int cellCap = g->cellCap;
+    uint32_t* out = cellKeys + cellGlobal * cellCap;
     unsigned long long keepIni = 0ull, keepMin = 0ull;
     int cntIni = 0, cntMin = 0;
-    for (int p = 0; p < steps; p++) {
-        const int y = p * rowsPerStep + ly;
+    const bool listed = nCorn <= CORN_CAP;
+    const int rounds = listed ? (nCorn + 63) >> 6 : steps;
+    for (int p = 0; p < rounds; p++) {
         bool lm = false, li = false;
-        if (lx < cw && y < ch) {
-            const uint8_t* sp = &score[(y + 1) * SCORE_PITCH + lx + 1];
-            const int s = sp[0];
-            if (s > 0) {
+        int px = lx, py = p * rowsPerStep + ly;
+        bool in = lx < cw && py < ch;
+        if (listed) {
+            in = p * 64 + lane < nCorn;
+            const unsigned q = in ? corn[p * 64 + lane] : 0u;
+            px = q & 255;
+            py = q >> 8;
+        }
+        if (in) {
+            const uint8_t* sp = &score[(py + 1) * SCORE_PITCH + px + 1];
+            const int sc = sp[0];
+            if (sc > 0) {
                 const int nb = max(max(imax3(sp[-SCORE_PITCH - 1], sp[-SCORE_PITCH], sp[-SCORE_PITCH + 1]),
                                        imax3(sp[SCORE_PITCH - 1], sp[SCORE_PITCH], sp[SCORE_PITCH + 1])),
                                    max((int)sp[-1], (int)sp[1]));
-                lm = s > nb;
-                li = lm && s >= iniTh;
+                lm = sc > nb;
+                li = lm && sc >= iniTh;
             }
         }
         keepMin |= (unsigned long long)lm << p;
@@ -220,17 +246,20 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(const OrbGeom* _
     }
     const unsigned long long keep = cntIni > 0 ? keepIni : keepMin;  // fallback decided after suppression, :852
     const int total = cntIni > 0 ? cntIni : cntMin;
-    const int cellCap = g->cellCap;
-    uint32_t* out = cellKeys + cellGlobal * cellCap;
     int run = 0;
-    for (int p = 0; p < steps; p++) {
+    for (int p = 0; p < rounds; p++) {
         const bool f = (keep >> p) & 1ull;
         const unsigned long long b = __ballot(f);
         if (f) {
-            const int y = p * rowsPerStep + ly;
+            int px = lx, py = p * rowsPerStep + ly;
+            if (listed) {
+                const unsigned q = corn[p * 64 + lane];
+                px = q & 255;
+                py = q >> 8;
+            }
             const int pos = run + __popcll(b & below);
-            const int s = score[(y + 1) * SCORE_PITCH + lx + 1];
-            if (pos < cellCap) out[pos] = (uint32_t)lx | ((uint32_t)y << 8) | ((uint32_t)s << 16);
+            const int sc = score[(py + 1) * SCORE_PITCH + px + 1];
+            if (pos < cellCap) out[pos] = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)sc << 16);
         }
         run += __popcll(b);
     }

@@ -106,6 +106,43 @@ def test_extract_stages_and_end_to_end(hip, oracle, preset, case):
     c.close()
 
 
+def _special_images(w, h):
+    rng = splitmix64(0xFA57, w * h)
+    noise = (rng & np.uint64(255)).astype(np.uint8).reshape(h, w)                 # corner-dense everywhere
+    dots = np.full((h, w), 60, np.uint8)
+    dots[::4, ::4] = 230                                                           # isolated maxima on a lattice
+    flat = np.full((h, w), 128, np.uint8)                                          # nothing at all
+    faint = (120 + (rng >> np.uint64(8)) % np.uint64(12)).astype(np.uint8).reshape(h, w)  # only minThFAST finds corners
+    half = noise.copy()
+    half[:, w // 2:] = 90                                                          # dense and empty cells side by side
+    return {"noise": noise, "dots": dots, "flat": flat, "faint": faint, "half": half}
+
+
+@pytest.mark.parametrize("preset", ["fork", "canonical"])
+def test_extract_special_images(hip, oracle, preset):
+    """Images that drive the FAST kernel through its rare paths: cells with more corners than its
+    corner list holds, cells with none, cells where only the minThFAST pass finds corners."""
+    w, h = 320, 240
+    imgs = _special_images(w, h)
+    dense = oracle.fast(imgs["noise"], 7, nms=False)
+    assert len(dense) > 0.3 * w * h, "the noise image is meant to be corner-dense (%d corners)" % len(dense)
+    c = _ctx(hip, preset, 1000, 4, w, h)
+    e = oracle.Extractor(1000, 1.2, 4, 20, 7, PRESETS[preset])
+    for name, img in imgs.items():
+        kg, dg = c.extract(img)
+        ko, do = e.extract(img)
+        for l in range(4):
+            xs, ys, sc = c.fast_keys(0, l)
+            ref = e.level_keys(l, after_quadtree=False)
+            assert len(xs) == len(ref), "%s level %d: %d FAST keys, oracle %d" % (name, l, len(xs), len(ref))
+            np.testing.assert_array_equal(xs, ref["x"].astype(np.int32), err_msg="%s FAST x level %d" % (name, l))
+            np.testing.assert_array_equal(ys, ref["y"].astype(np.int32), err_msg="%s FAST y level %d" % (name, l))
+            np.testing.assert_array_equal(sc, ref["response"].astype(np.int32), err_msg="%s FAST score level %d" % (name, l))
+        assert_kps_equal(kg, ko, name)
+        np.testing.assert_array_equal(dg, do, err_msg="descriptors " + name)
+    c.close()
+
+
 def test_extract_batch_equals_single(hip, oracle):
     n = 5
     c = _ctx(hip, "fork", batch=n)
