@@ -10,39 +10,43 @@
 
 #include "orb_internal.h"
 
-// Resize, both interpolation modes.  One workgroup produces a 64x16 destination tile: the source
-// rectangle its taps can touch (orb_resize_span, a superset checked against the tap tables on the
-// host) is fetched into LDS as whole dwords, the tile's tap entries likewise, and every thread then
-// computes four horizontally adjacent destination pixels from LDS and stores them as one dword.
-//
-// area:   dst(dx,dy) = saturate(round_half_even( sum_j beta_j * ( sum_k src(sx_k, sy_j) * alpha_k ) ))
-// linear: 11-bit weights, (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2
+// Resize, both interpolation modes, separably.  One workgroup produces a 64x16 destination tile:
+// the source rectangle its taps can touch (orb_resize_span, a superset checked against the tap
+// tables on the host) is fetched into LDS as whole dwords; a horizontal pass evaluates, for every
+// staged source row and every destination column, the row's contribution
+//   area:   buf = sum_k src(sx_k, row) * alpha_k        (float, each product and sum rounded)
+//   linear: H   = src(s0, row) * a0 + src(s1, row) * a1 (11-bit weights)
+// into LDS, and a vertical pass combines the rows of each destination pixel,
+//   area:   saturate(round_half_even(sum_j beta_j * buf_j))
+//   linear: (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2
+// four adjacent pixels per thread, stored as one dword.  This is the order cv::resize itself works in,
+// so sharing the horizontal results between destination rows changes nothing.
 template <bool AREA>
 __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict__ src, int sw, int sh, int sstride,
                                                       int64_t sFrame, uint8_t* __restrict__ dst, int dw, int dh,
                                                       int dpitch, int64_t dFrame, const void* __restrict__ xtab,
                                                       const void* __restrict__ ytab, double scaleX, double scaleY,
-                                                      int tp) {
+                                                      int tp, int rowsMax) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
-    OrbAreaTap* s_xa = (OrbAreaTap*)s_mem;
-    OrbAreaTap* s_ya = s_xa + ORB_RS_TW;
-    OrbLinTap* s_xl = (OrbLinTap*)s_mem;
-    OrbLinTap* s_yl = s_xl + ORB_RS_TW;
+    OrbAreaTap* s_ya = (OrbAreaTap*)s_mem;
+    OrbLinTap* s_yl = (OrbLinTap*)s_mem;
     uint8_t* tile = s_mem + ORB_RS_TAP_BYTES;
+    float* bufF = (float*)(tile + (((size_t)tp * rowsMax + 15) & ~(size_t)15));  // [rowsMax][ORB_RS_TW]
+    int* bufI = (int*)bufF;
     const int t = threadIdx.x;
     const int x0 = blockIdx.x * ORB_RS_TW, y0 = blockIdx.y * ORB_RS_TH;
     const int x1 = min(x0 + ORB_RS_TW, dw), y1 = min(y0 + ORB_RS_TH, dh);
-    if (t < ORB_RS_TW) {
-        if (x0 + t < dw) {
-            if (AREA) s_xa[t] = ((const OrbAreaTap*)xtab)[x0 + t];
-            else s_xl[t] = ((const OrbLinTap*)xtab)[x0 + t];
-        }
-    } else if (t < ORB_RS_TW + ORB_RS_TH) {
-        const int r = t - ORB_RS_TW;
-        if (y0 + r < dh) {
-            if (AREA) s_ya[r] = ((const OrbAreaTap*)ytab)[y0 + r];
-            else s_yl[r] = ((const OrbLinTap*)ytab)[y0 + r];
-        }
+    const int dx = t & 63, q = t >> 6;
+    const bool colValid = x0 + dx < dw;
+    OrbAreaTap txa = {};
+    OrbLinTap txl = {};
+    if (colValid) {
+        if (AREA) txa = ((const OrbAreaTap*)xtab)[x0 + dx];
+        else txl = ((const OrbLinTap*)xtab)[x0 + dx];
+    }
+    if (t < ORB_RS_TH && y0 + t < dh) {
+        if (AREA) s_ya[t] = ((const OrbAreaTap*)ytab)[y0 + t];
+        else s_yl[t] = ((const OrbLinTap*)ytab)[y0 + t];
     }
     int sx0, sx1, sy0, sy1;
     orb_resize_span(x0, x1, scaleX, sw, &sx0, &sx1);
@@ -67,46 +71,55 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
         *(uint32_t*)&tile[r * tp + 4 * d] = v;
     }
     __syncthreads();
-    const int cg = t & 15, row = t >> 4;
-    const int x = x0 + 4 * cg, y = y0 + row;
-    if (x >= dw || y >= dh) return;
-    const uint8_t* T = tile - (int64_t)sy0 * tp - sxa;  // T[sy * tp + sx] is source pixel (sx, sy)
-    uint32_t outw = 0u;
-    if (AREA) {
-        const OrbAreaTap ty = s_ya[row];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (x + i >= dw) break;
-            const OrbAreaTap tx = s_xa[4 * cg + i];
-            float sum = 0.f;
-#pragma unroll
-            for (int j = 0; j < ORB_MAX_TAPS; j++) {
-                if (ty.a[j] == 0.f) break;
-                const uint8_t* rowp = T + ty.si[j] * tp;
+    // horizontal pass: column dx of every staged row (wave q takes rows q, q + 4, ...)
+    if (colValid) {
+        for (int r = q; r < nrows; r += 4) {
+            const uint8_t* rowp = tile + r * tp - sxa;  // rowp[sx] is source pixel (sx, sy0 + r)
+            if (AREA) {
                 float buf = 0.f;
 #pragma unroll
                 for (int k = 0; k < ORB_MAX_TAPS; k++) {
-                    if (tx.a[k] == 0.f) break;
-                    buf = __fadd_rn(buf, __fmul_rn((float)rowp[tx.si[k]], tx.a[k]));
+                    if (txa.a[k] == 0.f) break;
+                    buf = __fadd_rn(buf, __fmul_rn((float)rowp[txa.si[k]], txa.a[k]));
                 }
-                const float term = __fmul_rn(ty.a[j], buf);
-                sum = (j == 0) ? term : __fadd_rn(sum, term);
+                bufF[r * ORB_RS_TW + dx] = buf;
+            } else {
+                bufI[r * ORB_RS_TW + dx] = rowp[txl.s0] * txl.a0 + rowp[txl.s1] * txl.a1;
             }
-            int v = (int)rintf(sum);
+        }
+    }
+    __syncthreads();
+    // vertical pass: four adjacent columns of one destination row per thread
+    const int cg = t & 15, row = t >> 4;
+    const int x = x0 + 4 * cg, y = y0 + row;
+    if (x >= dw || y >= dh) return;
+    uint32_t outw = 0u;
+    if (AREA) {
+        const OrbAreaTap ty = s_ya[row];
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < ORB_MAX_TAPS; j++) {
+            if (ty.a[j] == 0.f) break;
+            const float4 b = *(const float4*)&bufF[(ty.si[j] - sy0) * ORB_RS_TW + 4 * cg];
+            const float term[4] = {__fmul_rn(ty.a[j], b.x), __fmul_rn(ty.a[j], b.y), __fmul_rn(ty.a[j], b.z),
+                                   __fmul_rn(ty.a[j], b.w)};
+#pragma unroll
+            for (int i = 0; i < 4; i++) sum[i] = (j == 0) ? term[i] : __fadd_rn(sum[i], term[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int v = (int)rintf(sum[i]);
             v = v < 0 ? 0 : (v > 255 ? 255 : v);
             outw |= (uint32_t)v << (8 * i);
         }
     } else {
         const OrbLinTap ty = s_yl[row];
-        const uint8_t* S0 = T + ty.s0 * tp;
-        const uint8_t* S1 = T + ty.s1 * tp;
+        const int4 h0 = *(const int4*)&bufI[(ty.s0 - sy0) * ORB_RS_TW + 4 * cg];
+        const int4 h1 = *(const int4*)&bufI[(ty.s1 - sy0) * ORB_RS_TW + 4 * cg];
+        const int H0[4] = {h0.x, h0.y, h0.z, h0.w}, H1[4] = {h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            if (x + i >= dw) break;
-            const OrbLinTap tx = s_xl[4 * cg + i];
-            const int H0 = S0[tx.s0] * tx.a0 + S0[tx.s1] * tx.a1;
-            const int H1 = S1[tx.s0] * tx.a0 + S1[tx.s1] * tx.a1;
-            const int v = (((ty.a0 * (H0 >> 4)) >> 16) + ((ty.a1 * (H1 >> 4)) >> 16) + 2) >> 2;
+            const int v = (((ty.a0 * (H0[i] >> 4)) >> 16) + ((ty.a1 * (H1[i] >> 4)) >> 16) + 2) >> 2;
             outw |= (uint32_t)(v & 255) << (8 * i);
         }
     }
@@ -178,7 +191,7 @@ static int launch_resize(bool area, const uint8_t* src, int sw, int sh, int sstr
     int tp = 0, rows = 0;
     orb_resize_tile_extent(sw, dw, scaleX, ORB_RS_TW, true, &tp);
     orb_resize_tile_extent(sh, dh, scaleY, ORB_RS_TH, false, &rows);
-    const size_t lds = ORB_RS_TAP_BYTES + (size_t)tp * rows;
+    const size_t lds = ORB_RS_TAP_BYTES + (((size_t)tp * rows + 15) & ~(size_t)15) + (size_t)rows * ORB_RS_TW * 4;
     if (lds > 64 * 1024) {
         orb_set_error("resize %dx%d -> %dx%d: source tile of %zu bytes does not fit the kernel's LDS budget", sw, sh, dw,
                       dh, lds);
@@ -187,10 +200,10 @@ static int launch_resize(bool area, const uint8_t* src, int sw, int sh, int sstr
     dim3 grid((dw + ORB_RS_TW - 1) / ORB_RS_TW, (dh + ORB_RS_TH - 1) / ORB_RS_TH, nframes);
     if (area)
         hipLaunchKernelGGL(k_resize_tiled<true>, grid, dim3(256), lds, st, src, sw, sh, sstride, sFrame, dst, dw, dh,
-                           dpitch, dFrame, xt, yt, scaleX, scaleY, tp);
+                           dpitch, dFrame, xt, yt, scaleX, scaleY, tp, rows);
     else
         hipLaunchKernelGGL(k_resize_tiled<false>, grid, dim3(256), lds, st, src, sw, sh, sstride, sFrame, dst, dw, dh,
-                           dpitch, dFrame, xt, yt, scaleX, scaleY, tp);
+                           dpitch, dFrame, xt, yt, scaleX, scaleY, tp, rows);
     return check_launch("resize");
 }
 

@@ -63,7 +63,7 @@ struct OrbLinTap {   // one destination index of the linear resize
 // position is allowed for.  The host checks the tap tables against it before the first launch.
 #define ORB_RS_TW 64
 #define ORB_RS_TH 16
-#define ORB_RS_TAP_BYTES ((ORB_RS_TW + ORB_RS_TH) * 32)
+#define ORB_RS_TAP_BYTES (ORB_RS_TH * 32)   // the tile's vertical taps, staged in LDS
 #ifdef __HIPCC__
 #define ORB_HD __host__ __device__
 #else
