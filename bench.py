@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step and GPU")
+    ap.add_argument("--batch", type=int, default=256, help="frames per step and GPU")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--nfeatures", type=int, default=1000)
@@ -110,7 +110,6 @@ def main():
         step()
     torch.cuda.synchronize()
     ctx.check_last_batch()
-    ctx.enable_stage_timing(True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -119,6 +118,14 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
+    ctx.check_last_batch()
+    # Per-kernel durations for the roofline: the same steps again with HIP events between the stages.
+    # In that mode the library enqueues a batch as one group on one stream, so that each event pair
+    # brackets exactly one stage; the timed loop above lets it overlap groups of frames on several streams.
+    ctx.enable_stage_timing(True)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
     stage_ms, nrec = ctx.stage_timings()
     ctx.enable_stage_timing(False)
     ctx.check_last_batch()
@@ -136,13 +143,31 @@ def main():
         "describe": nkp * (43 * 43 + 28 + 32),                      # source window + keypoint + descriptor
     }
     dom = max(stage_ms, key=lambda k: stage_ms[k])
-    kernel_name = {"pyramid": "k_resize_area x7", "fast": "k_fast_cells", "quadtree": "k_quadtree", "describe": "k_describe"}[dom]
+    kernel_name = {"pyramid": "k_resize_tiled x7", "fast": "k_fast_cells", "quadtree": "k_quadtree", "describe": "k_describe"}[dom]
     achieved = stage_bytes[dom] * B / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
+    # HBM-side bytes and VALU instruction counts of the same kernel from the committed rocprofv3 --pmc passes
+    # (tools/pmc_collect.sh; counters are per launch at the batch size recorded in the file, scaled to this batch).
+    traffic, valu = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_per_kernel.json")
+    if os.path.exists(pmc_path) and dom != "pyramid" and args.width == 640 and args.height == 480 and args.nfeatures == 1000:
+        with open(pmc_path) as fh:
+            pk = json.load(fh).get(kernel_name)
+        if pk:
+            k = B / pk["batch"]
+            cn = pk["counters_per_launch"]
+            if "FETCH_SIZE" in cn and "WRITE_SIZE" in cn:
+                traffic = int((cn["FETCH_SIZE"] + cn["WRITE_SIZE"]) * 1024 * k)
+            if "SQ_INSTS_VALU" in cn:
+                wi = cn["SQ_INSTS_VALU"] * k
+                # one wave-instruction holds a SIMD's 16-lane ALU for 4 cycles; 1024 SIMDs at 2.4 GHz
+                valu = {"wave_instructions_per_launch": int(wi), "issue_cycles_per_instruction": 4,
+                        "util": round(wi * 4 / (1024 * 2.4e9 * stage_ms[dom] * 1e-3), 4)}
     roofline = {
         "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "valu_issue": valu,
         "algorithmic_bytes_per_launch": int(stage_bytes[dom] * B), "launch_ms": round(stage_ms[dom], 4),
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}, "stage_batches": nrec,
+        "stage_timing": "HIP events between the stages, same steps repeated after the timed loop with group overlap off",
     }
 
     # ---- brute-force Hamming ------------------------------------------------------------

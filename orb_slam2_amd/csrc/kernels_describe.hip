@@ -118,7 +118,8 @@ static __device__ __forceinline__ int wave_sum(int v) {
 __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __restrict__ g,
                                                              const uint8_t* __restrict__ img0, int stride0,
                                                              int64_t frameStride0, const uint8_t* __restrict__ pyr,
-                                                             int nframes, const uint32_t* __restrict__ selXY,
+                                                             int frame0, int nframes,
+                                                             const uint32_t* __restrict__ selXY,
                                                              const int* __restrict__ selScore,
                                                              const int* __restrict__ levelCount,
                                                              orb_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
@@ -129,10 +130,10 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     __shared__ __attribute__((aligned(16))) uint8_t s_bl[DESC_WAVES][BL_N * BL_P];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int outCapFrame = g->outCapFrame, nlevels = g->nlevels;
-    const int64_t slotGlobal = (int64_t)blockIdx.x * DESC_WAVES + wave;
-    if (slotGlobal >= (int64_t)nframes * outCapFrame) return;
-    const int frame = (int)(slotGlobal / outCapFrame);
-    const int slot = (int)(slotGlobal - (int64_t)frame * outCapFrame);
+    const int64_t slotLocal = (int64_t)blockIdx.x * DESC_WAVES + wave;
+    if (slotLocal >= (int64_t)nframes * outCapFrame) return;
+    const int frame = frame0 + (int)(slotLocal / outCapFrame);
+    const int slot = (int)(slotLocal % outCapFrame);
     int level = 0;
     for (int l = 1; l < nlevels; l++)
         if (slot >= g->lv[l].outBase) level = l;
@@ -315,7 +316,7 @@ int orb_launch_describe(const OrbBatch& b) {
     const int64_t slots = (int64_t)b.nframes * g.outCapFrame;
     const int64_t blocks = (slots + DESC_WAVES - 1) / DESC_WAVES;
     hipLaunchKernelGGL(k_describe, dim3((unsigned)blocks), dim3(64 * DESC_WAVES), 0, (hipStream_t)b.stream, b.d_geom,
-                       b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.nframes, b.d_selXY, b.d_selScore,
+                       b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, b.nframes, b.d_selXY, b.d_selScore,
                        b.d_levelCount, b.d_kps, b.d_desc, b.capPerFrame, b.d_nOut, b.d_error);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -79,18 +79,20 @@ static __device__ __forceinline__ int fast_score(const uint8_t* c) {
 __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(const OrbGeom* __restrict__ g,
                                                                const uint8_t* __restrict__ img0, int stride0,
                                                                int64_t frameStride0, const uint8_t* __restrict__ pyr,
-                                                               int nframes, uint32_t* __restrict__ cellKeys,
+                                                               int frame0, int nframes,
+                                                               uint32_t* __restrict__ cellKeys,
                                                                int* __restrict__ cellCount) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[FAST_WAVES][TILE_ROWS * TILE_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[FAST_WAVES][SCORE_ROWS * SCORE_PITCH];
     __shared__ uint16_t s_cand[FAST_WAVES][128];
     __shared__ uint16_t s_corn[FAST_WAVES][CORN_CAP];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t cellGlobal = (int64_t)blockIdx.x * FAST_WAVES + wave;
+    const int64_t cellLocal = (int64_t)blockIdx.x * FAST_WAVES + wave;
     const int cellsPerFrame = g->cellsPerFrame;
-    if (cellGlobal >= (int64_t)nframes * cellsPerFrame) return;  // whole wave leaves; no workgroup barrier below
-    const int frame = (int)(cellGlobal / cellsPerFrame);
-    const int c = (int)(cellGlobal - (int64_t)frame * cellsPerFrame);
+    if (cellLocal >= (int64_t)nframes * cellsPerFrame) return;  // whole wave leaves; no workgroup barrier below
+    const int frame = frame0 + (int)(cellLocal / cellsPerFrame);
+    const int c = (int)(cellLocal % cellsPerFrame);
+    const int64_t cellGlobal = (int64_t)frame * cellsPerFrame + c;
     int level = 0;
     for (int l = 1; l < g->nlevels; l++)
         if (c >= g->lv[l].cellBase) level = l;
@@ -271,7 +273,7 @@ int orb_launch_fast(const OrbBatch& b) {
     const int64_t cells = (int64_t)b.nframes * g.cellsPerFrame;
     const int64_t blocks = (cells + FAST_WAVES - 1) / FAST_WAVES;
     hipLaunchKernelGGL(k_fast_cells, dim3((unsigned)blocks), dim3(64 * FAST_WAVES), 0, (hipStream_t)b.stream, b.d_geom,
-                       b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.nframes, b.d_cellKeys, b.d_cellCount);
+                       b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, b.nframes, b.d_cellKeys, b.d_cellCount);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         orb_set_error("fast launch failed: %s", hipGetErrorString(e));

@@ -219,8 +219,9 @@ int orb_launch_pyramid(const OrbBatch& b) {
         const int64_t sFrame = (l == 1) ? b.frameStride0 : P.frameStride;
         const void* xt = area ? (const void*)(b.d_areaTaps + D.tabX) : (const void*)(b.d_linTaps + D.tabX);
         const void* yt = area ? (const void*)(b.d_areaTaps + D.tabY) : (const void*)(b.d_linTaps + D.tabY);
-        int rc = launch_resize(area, src, P.w, P.h, sstride, sFrame, b.d_pyr + D.off, D.w, D.h, D.pitch, D.frameStride,
-                               xt, yt, b.nframes, st);
+        int rc = launch_resize(area, src + b.frame0 * sFrame, P.w, P.h, sstride, sFrame,
+                               b.d_pyr + D.off + b.frame0 * D.frameStride, D.w, D.h, D.pitch, D.frameStride, xt, yt,
+                               b.nframes, st);
         if (rc) return rc;
     }
     return ORB_OK;

@@ -67,6 +67,9 @@ struct DevBuf {
     }
 };
 
+#define ORB_MAX_PARTS 4
+#define ORB_MIN_PART_FRAMES 8   // groups smaller than this do not fill the device; the batch is then not split
+
 struct orb_ctx {
     orb_params prm;
     double scaleFactorD;  // the reference keeps scaleFactor in a double member (include/ORBextractor.h:88)
@@ -78,6 +81,12 @@ struct orb_ctx {
     std::vector<OrbAreaTap> areaTaps;
     std::vector<OrbLinTap> linTaps;
     hipStream_t stream = nullptr;
+    // A batch is enqueued as up to ORB_MAX_PARTS groups of frames, the first on the caller's stream and
+    // the others on these, so that the latency-bound stages of one group (quadtree, small pyramid
+    // levels) run under the throughput-bound stages of another.
+    hipStream_t aux[ORB_MAX_PARTS - 1] = {};
+    hipEvent_t evFork = nullptr, evJoin[ORB_MAX_PARTS - 1] = {};
+    int parts = 3;
     DevBuf dGeom, dAreaTaps, dLinTaps, dInput, dPyr, dCellKeys, dCellCount, dSort, dNodes, dInts,
         dSelXY, dSelScore, dLevelCount, dLevelKeys, dError, dKps, dDesc, dNOut, dTmpA, dTmpB;
     int lastFrames = 0;
@@ -461,6 +470,12 @@ extern "C" int orb_create(const orb_params* prm, orb_ctx** out) {
     c->prm = *prm;
     build_tables(c);
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < ORB_MAX_PARTS - 1; i++) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->evJoin[i], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+    if (const char* e = getenv("ORBHIP_PARTS")) c->parts = std::max(1, std::min(ORB_MAX_PARTS, atoi(e)));
     // size everything for the largest announced frame and batch now, so steady-state calls allocate nothing
     int rc = compute_geom(c, prm->max_width, prm->max_height);
     if (rc == ORB_OK) rc = ensure_buffers(c, prm->max_batch);
@@ -491,6 +506,11 @@ extern "C" void orb_destroy(orb_ctx* c) {
     for (DevBuf* b : bufs) b->release();
     if (c->matchState) orb_match_state_free(c->matchState);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    for (int i = 0; i < ORB_MAX_PARTS - 1; i++) {
+        if (c->evJoin[i]) (void)hipEventDestroy(c->evJoin[i]);
+        if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
+    }
+    if (c->evFork) (void)hipEventDestroy(c->evFork);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -548,6 +568,7 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
     b.d_img0 = d_img0;
     b.stride0 = stride;
     b.frameStride0 = frameStride;
+    b.frame0 = 0;
     b.nframes = n;
     b.d_pyr = (uint8_t*)c->dPyr.p;
     b.d_areaTaps = (const OrbAreaTap*)c->dAreaTaps.p;
@@ -570,20 +591,45 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
     c->lastImg0 = d_img0;
     c->lastStride0 = stride;
     c->lastFrameStride0 = frameStride;
-    hipEvent_t* ev = nullptr;
-    if (c->timing) {
-        ev = &c->events[(size_t)(c->evCount % ORB_EV_RING) * 5];
+    if (c->timing) {  // stage timing: the whole batch as one group, stages back to back on the caller's stream
+        hipEvent_t* ev = &c->events[(size_t)(c->evCount % ORB_EV_RING) * 5];
         c->evCount++;
         HIP_TRY(hipEventRecord(ev[0], st));
+        if ((rc = orb_launch_pyramid(b))) return rc;
+        HIP_TRY(hipEventRecord(ev[1], st));
+        if ((rc = orb_launch_fast(b))) return rc;
+        HIP_TRY(hipEventRecord(ev[2], st));
+        if ((rc = orb_launch_quadtree(b))) return rc;
+        HIP_TRY(hipEventRecord(ev[3], st));
+        if ((rc = orb_launch_describe(b))) return rc;
+        HIP_TRY(hipEventRecord(ev[4], st));
+        return ORB_OK;
     }
-    if ((rc = orb_launch_pyramid(b))) return rc;
-    if (ev) HIP_TRY(hipEventRecord(ev[1], st));
-    if ((rc = orb_launch_fast(b))) return rc;
-    if (ev) HIP_TRY(hipEventRecord(ev[2], st));
-    if ((rc = orb_launch_quadtree(b))) return rc;
-    if (ev) HIP_TRY(hipEventRecord(ev[3], st));
-    if ((rc = orb_launch_describe(b))) return rc;
-    if (ev) HIP_TRY(hipEventRecord(ev[4], st));
+    const int parts = std::max(1, std::min(c->parts, n / ORB_MIN_PART_FRAMES));
+    if (parts > 1) HIP_TRY(hipEventRecord(c->evFork, st));
+    // stage by stage across the groups, so that the queues hold comparable work at any time
+    OrbBatch pb[ORB_MAX_PARTS];
+    for (int i = 0; i < parts; i++) {
+        pb[i] = b;
+        pb[i].frame0 = (int)((int64_t)n * i / parts);
+        pb[i].nframes = (int)((int64_t)n * (i + 1) / parts) - pb[i].frame0;
+        if (i > 0) {
+            pb[i].stream = c->aux[i - 1];
+            HIP_TRY(hipStreamWaitEvent(c->aux[i - 1], c->evFork, 0));
+        }
+    }
+    for (int i = 0; i < parts; i++)
+        if ((rc = orb_launch_pyramid(pb[i]))) return rc;
+    for (int i = 0; i < parts; i++)
+        if ((rc = orb_launch_fast(pb[i]))) return rc;
+    for (int i = 0; i < parts; i++)
+        if ((rc = orb_launch_quadtree(pb[i]))) return rc;
+    for (int i = 0; i < parts; i++)
+        if ((rc = orb_launch_describe(pb[i]))) return rc;
+    for (int i = 1; i < parts; i++) {
+        HIP_TRY(hipEventRecord(c->evJoin[i - 1], c->aux[i - 1]));
+        HIP_TRY(hipStreamWaitEvent(st, c->evJoin[i - 1], 0));
+    }
     return ORB_OK;
 }
 

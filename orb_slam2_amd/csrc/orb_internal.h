@@ -107,7 +107,7 @@ struct OrbBatch {  // everything one extraction launch sequence needs
     const uint8_t* d_img0;      // level 0 = the caller's frames
     int stride0;
     int64_t frameStride0;
-    int nframes;
+    int frame0, nframes;        // this launch sequence covers frames [frame0, frame0 + nframes) of the batch
     uint8_t* d_pyr;             // levels >= 1, level-major
     const OrbAreaTap* d_areaTaps;
     const OrbLinTap* d_linTaps;
