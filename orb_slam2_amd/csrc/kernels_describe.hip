@@ -109,6 +109,16 @@ static __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+// sum of the two 16-bit products of a and b, plus c (v_dot2_u32_u16)
+static __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b), c, false);
+}
+// sum of the four byte products of a and b, plus c (v_dot4_u32_u8)
+static __device__ __forceinline__ uint32_t dot4_u8(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot4(a, b, c, false);
+}
+
 static __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -180,11 +190,18 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
                           (((unsigned long long)img) & 3ull) == 0;
     const int off = fastLoad ? (wx0 - xa) : 0;
     if (fastLoad) {
-        const uint8_t* src = img + (int64_t)wy0 * pitch + xa;
-        uint32_t* raw32 = (uint32_t*)raw;
-        for (int k = lane; k < RAW_N * (RAW_P / 4); k += 64) {
-            const int r = k / (RAW_P / 4), d = k - r * (RAW_P / 4);
-            raw32[k] = *(const uint32_t*)(src + (int64_t)r * pitch + 4 * d);
+        // lane = (row within a group of five, dword); nine groups cover the 43 rows, all loads in flight at once
+        const int rr = lane / (RAW_P / 4), d = lane - rr * (RAW_P / 4);
+        if (rr < 5) {
+            const uint8_t* src = img + (int64_t)(wy0 + rr) * pitch + xa + 4 * d;
+            uint32_t* dstw = (uint32_t*)raw + rr * (RAW_P / 4) + d;
+            uint32_t v[9];
+#pragma unroll
+            for (int it = 0; it < 9; it++)
+                if (rr + 5 * it < RAW_N) v[it] = *(const uint32_t*)(src + (int64_t)(5 * it) * pitch);
+#pragma unroll
+            for (int it = 0; it < 9; it++)
+                if (rr + 5 * it < RAW_N) dstw[it * 5 * (RAW_P / 4)] = v[it];
         }
     } else {
         for (int k = lane; k < RAW_N * RAW_N; k += 64) {
@@ -206,18 +223,16 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
             const int v = r - 15, av = v < 0 ? -v : v;
             const int lim = (int)((um >> (4 * av)) & 15ull);
             const uint32_t w = raw32[(6 + r) * (RAW_P / 4) + q];
-            const int u0 = 4 * q - off - 21;
-            int rowSum = 0;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int u = u0 + c, au = u < 0 ? -u : u;
-                const int val = (int)((w >> (8 * c)) & 255u);
-                if (au <= lim) {
-                    m10 += u * val;
-                    rowSum += val;
-                }
+            const int u0 = 4 * q - off - 21;  // u of the dword's first byte
+            // bytes lo..hi of the dword lie inside the patch row (|u| <= lim)
+            const int lo = max(0, -lim - u0), hi = min(3, lim - u0);
+            if (lo <= hi) {
+                const uint32_t ones = (0x01010101u << (8 * lo)) & (0x01010101u >> (8 * (3 - hi)));
+                const uint32_t idx = (ones * 0xffu) & 0x03020100u;
+                const int rowSum = (int)dot4_u8(w, ones, 0u);
+                m10 += u0 * rowSum + (int)dot4_u8(w, idx, 0u);
+                m01 += v * rowSum;
             }
-            m01 += v * rowSum;
         }
     }
     m10 = wave_sum(m10);
@@ -230,26 +245,27 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     // the window; nothing reads them.
     const bool legacy = (g->quirks & ORB_Q_GAUSS_LEGACY) != 0;
     const uint32_t k0 = 18, k1 = 34, k2 = legacy ? 49 : 48, k3 = legacy ? 55 : 56;
+    const uint32_t wA = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);  // taps 0..3 against four consecutive bytes
+    const uint32_t wB = k2 | (k1 << 8) | (k0 << 16);               // taps 4..6
     const uint32_t* raw32 = (const uint32_t*)s_raw[wave];
     uint32_t* hb32 = (uint32_t*)hb;
     for (int k = lane; k < RAW_N * HGROUPS; k += 64) {
         const int r = k / HGROUPS, q = k - r * HGROUPS;
         const uint32_t* p = raw32 + r * (RAW_P / 4) + q;
         const uint32_t A = p[q > 0 ? -1 : 0], B = p[0], C = p[1];
-        const uint32_t e0 = (A >> 8) & 255u, e1 = (A >> 16) & 255u, e2 = A >> 24;
-        const uint32_t e3 = B & 255u, e4 = (B >> 8) & 255u, e5 = (B >> 16) & 255u, e6 = B >> 24;
-        const uint32_t e7 = C & 255u, e8 = (C >> 8) & 255u, e9 = (C >> 16) & 255u;
-        const uint32_t o0 = k0 * (e0 + e6) + k1 * (e1 + e5) + k2 * (e2 + e4) + k3 * e3;
-        const uint32_t o1 = k0 * (e1 + e7) + k1 * (e2 + e6) + k2 * (e3 + e5) + k3 * e4;
-        const uint32_t o2 = k0 * (e2 + e8) + k1 * (e3 + e7) + k2 * (e4 + e6) + k3 * e5;
-        const uint32_t o3 = k0 * (e3 + e9) + k1 * (e4 + e8) + k2 * (e5 + e7) + k3 * e6;
+        // output m of the group sums bytes m-3 .. m+3 around column 4q + m: two unaligned dwords each
+        const uint32_t o0 = dot4_u8(__builtin_amdgcn_alignbyte(B, A, 1), wA, dot4_u8(__builtin_amdgcn_alignbyte(C, B, 1), wB, 0u));
+        const uint32_t o1 = dot4_u8(__builtin_amdgcn_alignbyte(B, A, 2), wA, dot4_u8(__builtin_amdgcn_alignbyte(C, B, 2), wB, 0u));
+        const uint32_t o2 = dot4_u8(__builtin_amdgcn_alignbyte(B, A, 3), wA, dot4_u8(__builtin_amdgcn_alignbyte(C, B, 3), wB, 0u));
+        const uint32_t o3 = dot4_u8(B, wA, dot4_u8(C, wB, 0u));
         uint2 o;
-        o.x = (o0 & 0xffffu) | (o1 << 16);
+        o.x = (o0 & 0xffffu) | (o1 << 16);  // 16-bit wrap-around as in the 8.8 fixed-point row filter (sums stay below 2^16 anyway)
         o.y = (o2 & 0xffffu) | (o3 << 16);
         *(uint2*)(hb32 + r * (HB_P / 2) + 2 * q) = o;
     }
     wave_lds_sync();
     uint32_t* bl32 = (uint32_t*)bl;
+    const uint32_t wP0 = k0 | (k1 << 16), wP1 = k2 | (k3 << 16), wP2 = k2 | (k1 << 16);  // row pairs (0,1) (2,3) (4,5)
     for (int k = lane; k < BL_N * HGROUPS; k += 64) {
         const int r = k / HGROUPS, q = k - r * HGROUPS;
         const uint32_t* p = hb32 + r * (HB_P / 2) + 2 * q;
@@ -258,16 +274,24 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
         for (int i = 0; i < 7; i++) h[i] = *(const uint2*)(p + i * (HB_P / 2));
         uint32_t packed = 0;
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            uint32_t s[7];
+        for (int half = 0; half < 2; half++) {  // dword `half` holds columns 2*half and 2*half + 1
+            uint32_t hw[7];
 #pragma unroll
-            for (int i = 0; i < 7; i++) {
-                const uint32_t w = (c & 2) ? h[i].y : h[i].x;
-                s[i] = (c & 1) ? (w >> 16) : (w & 0xffffu);
+            for (int i = 0; i < 7; i++) hw[i] = half ? h[i].y : h[i].x;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                // (row i, row i+1) of one column side by side; the seventh row is weighted inside its own dword
+                const uint32_t sel = c ? 0x07060302u : 0x05040100u;
+                const uint32_t p01 = __builtin_amdgcn_perm(hw[1], hw[0], sel);
+                const uint32_t p23 = __builtin_amdgcn_perm(hw[3], hw[2], sel);
+                const uint32_t p45 = __builtin_amdgcn_perm(hw[5], hw[4], sel);
+                uint32_t v = dot2_u16(hw[6], c ? (k0 << 16) : k0, 32768u);
+                v = dot2_u16(p45, wP2, v);
+                v = dot2_u16(p23, wP1, v);
+                v = dot2_u16(p01, wP0, v);
+                v >>= 16;
+                packed |= (v > 255u ? 255u : v) << (8 * (2 * half + c));
             }
-            uint32_t v = k0 * (s[0] + s[6]) + k1 * (s[1] + s[5]) + k2 * (s[2] + s[4]) + k3 * s[3];
-            v = (v + 32768u) >> 16;
-            packed |= (v > 255u ? 255u : v) << (8 * c);
         }
         bl32[r * (BL_P / 4) + q] = packed;
     }
