@@ -4,15 +4,25 @@
 // both on top of Frame::GetFeaturesInArea (src/Frame.cc:86-144) and the 64x48
 // bucket grid of include/Frame.h:16-17,96.
 //
-// One wavefront per frame pair.  The second frame's keypoints are sorted by
-// (grid column * 48 + grid row, keypoint index): GetFeaturesInArea visits
-// columns outermost, rows inside, indices inside a bucket in increasing order,
-// which is exactly ascending position in that sorted array.  A window query
-// therefore is, per grid column, one contiguous slice of the array, and "first
-// candidate wins on equal distance" is "smallest array position wins".  Queries
-// are resolved in index order because each accepted match changes what later
-// queries may take (vMatchedDistance / map-point occupancy); inside a query the
-// 64 lanes scan the candidates and reduce (distance, position) with shuffles.
+// Three kernels per call:
+//  1. k_grid_build (one workgroup per searched frame) sorts the frame's
+//     keypoints by (grid column * 48 + grid row, keypoint index).
+//     GetFeaturesInArea visits columns outermost, rows inside, indices inside a
+//     bucket in increasing order, which is exactly ascending position in that
+//     array; a window query is one contiguous slice of it with a row filter,
+//     and "first candidate wins on equal distance" is "smallest position wins".
+//  2. k_match_lists (one wavefront per query, all queries of all pairs in
+//     parallel) runs the window query and writes the query's candidates as
+//     (Hamming distance << 16 | position), in window order.  This is all of the
+//     descriptor work and does not depend on the order queries are resolved in.
+//  3. k_match_resolve (one workgroup per pair) walks the queries in index order,
+//     because each accepted match changes what later queries may take
+//     (vMatchedDistance / map-point occupancy): it filters the query's list by
+//     that state, reduces (distance, position) over the lanes and updates the
+//     state, all in LDS.  Queries with an empty list are skipped; three wavefronts
+//     stage the lists of the next 64 queries while one resolves the current 64.  The rotation histogram is filled afterwards from
+//     the recorded acceptances (the reference never removes a stolen match from
+//     rotHist, so every acceptance counts once).
 #include <hip/hip_runtime.h>
 
 #include <climits>
@@ -33,17 +43,6 @@
         }                                                                                               \
     } while (0)
 
-struct MatchLds {
-    uint32_t sorted[M_MAXKP];      // bucket << 16 | keypoint index, ascending (index < 65536)
-    float2 xy[M_MAXKP];            // keypoint position, by sorted position
-    uint8_t oct[M_MAXKP];          // keypoint octave, by sorted position
-    uint16_t cellStart[M_CELLS + 2];
-    uint16_t matchedDist[M_MAXKP]; // vMatchedDistance (0xFFFF = INT_MAX) / occupancy flag for the projected search
-    int16_t owner[M_MAXKP];        // vnMatches21 / query that owns the keypoint
-    uint16_t cand[M_MAXKP];        // sorted positions that passed the window test of the current query
-    int hist[ORB_HISTO];
-};
-
 static __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -51,105 +50,56 @@ static __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Minimum over the 64 lanes, returned to all of them: row shifts and row broadcasts through the DPP
+// path (no LDS round trips), then a read of lane 63.  Lanes a step does not write keep their value.
+template <int CTRL>
+static __device__ __forceinline__ uint32_t dpp_min_step(uint32_t v) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+    return min(v, o);
+}
 static __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
-    return v;
+    v = dpp_min_step<0x111>(v);  // row_shr:1
+    v = dpp_min_step<0x112>(v);  // row_shr:2
+    v = dpp_min_step<0x114>(v);  // row_shr:4
+    v = dpp_min_step<0x118>(v);  // row_shr:8   -> lane 15 of every row holds the row's minimum
+    v = dpp_min_step<0x142>(v);  // row_bcast:15 -> lane 31 / 63 hold the minimum of rows 0-1 / 2-3
+    v = dpp_min_step<0x143>(v);  // row_bcast:31 -> lane 63 holds the minimum of the wavefront
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// The two smallest of the wavefront's keys, given each lane's own two smallest (k1 <= k2), returned
+// to all lanes.  Keys are unique or 0xFFFFFFFF ("none").  Same DPP ladder; lanes a step does not feed
+// merge with "none", and the row broadcasts write only the rows that are meant to receive them.
+template <int CTRL, int ROWS>
+static __device__ __forceinline__ void dpp_top2_step(uint32_t& k1, uint32_t& k2) {
+    const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)k1, CTRL, ROWS, 0xf, false);
+    const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)k2, CTRL, ROWS, 0xf, false);
+    const uint32_t lo = min(k1, o1), hi = min(max(k1, o1), min(k2, o2));
+    k1 = lo;
+    k2 = hi;
+}
+static __device__ __forceinline__ void wave_top2_u32(uint32_t& k1, uint32_t& k2) {
+    dpp_top2_step<0x111, 0xf>(k1, k2);
+    dpp_top2_step<0x112, 0xf>(k1, k2);
+    dpp_top2_step<0x114, 0xf>(k1, k2);
+    dpp_top2_step<0x118, 0xf>(k1, k2);
+    dpp_top2_step<0x142, 0xa>(k1, k2);  // row_bcast:15 into rows 1 and 3
+    dpp_top2_step<0x143, 0xc>(k1, k2);  // row_bcast:31 into rows 2 and 3
+    k1 = (uint32_t)__builtin_amdgcn_readlane((int)k1, 63);
+    k2 = (uint32_t)__builtin_amdgcn_readlane((int)k2, 63);
+}
+
+// Orders LDS accesses of one wavefront for the compiler only: the hardware executes a wavefront's LDS
+// instructions in issue order, so a store by one lane is seen by later loads of the other lanes.
+static __device__ __forceinline__ void wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 struct Window {
     int x0, x1, y0, y1;  // bucket ranges [x0,x1) x [y0,y1); empty when x1 <= x0
 };
-
-// Sort the frame's keypoints into bucket order and build bucket start offsets.
-// Bucket assignment as the Frame constructor does it (PosInGrid): rounded
-// position, keypoints that fall outside the grid are left out.
-static __device__ void grid_build(MatchLds& S, const orb_keypoint* __restrict__ k2, int n2, float wInv, float hInv,
-                                  int lane, int* nIn) {
-    int np2 = 1;
-    while (np2 < n2) np2 <<= 1;
-    for (int i = lane; i < np2; i += 64) {
-        uint32_t key = 0xFFFFFFFFu;
-        if (i < n2) {
-            const int px = (int)roundf(__fmul_rn(k2[i].x, wInv));  // mnMinX = mnMinY = 0: no lens distortion
-            const int py = (int)roundf(__fmul_rn(k2[i].y, hInv));
-            if (px >= 0 && px < ORB_GRID_COLS && py >= 0 && py < ORB_GRID_ROWS)
-                key = ((uint32_t)(px * ORB_GRID_ROWS + py) << 16) | (uint32_t)i;
-        }
-        S.sorted[i] = key;
-    }
-    wave_lds_sync();
-    for (int k = 2; k <= np2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = lane; i < np2; i += 64) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const uint32_t a = S.sorted[i], b = S.sorted[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) {
-                        S.sorted[i] = b;
-                        S.sorted[l] = a;
-                    }
-                }
-            }
-            wave_lds_sync();
-        }
-    }
-    // bucket c starts at the first entry whose bucket is >= c
-    for (int c = lane; c <= M_CELLS; c += 64) {
-        int lo = 0, hi = n2;
-        const uint32_t key = (uint32_t)c << 16;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (S.sorted[mid] < key) lo = mid + 1; else hi = mid;
-        }
-        S.cellStart[c] = (uint16_t)lo;
-    }
-    wave_lds_sync();
-    *nIn = S.cellStart[M_CELLS];
-    for (int p = lane; p < *nIn; p += 64) {
-        const orb_keypoint kp = k2[S.sorted[p] & 0xFFFFu];
-        S.xy[p] = make_float2(kp.x, kp.y);
-        S.oct[p] = (uint8_t)(kp.octave < 0 ? 255 : (kp.octave > 254 ? 254 : kp.octave));
-    }
-    wave_lds_sync();
-}
-
-// Window query: collects into S.cand the sorted positions of the keypoints GetFeaturesInArea would
-// return (src/Frame.cc:110-136), in its order.  The buckets of the window's columns form one
-// contiguous slice of the sorted array; rows outside [y0, y1) are skipped.  Returns the count.
-static __device__ int window_candidates(MatchLds& S, const Window& w, float x, float y, float r, int minLevel,
-                                        int maxLevel, bool circ, int lane) {
-    if (w.x1 <= w.x0 || w.y1 <= w.y0) return 0;
-    const int lo = S.cellStart[w.x0 * ORB_GRID_ROWS + w.y0];
-    const int hi = S.cellStart[(w.x1 - 1) * ORB_GRID_ROWS + w.y1];
-    const bool checkLevels = minLevel >= 0 || maxLevel >= 0;
-    const float r2 = __fmul_rn(r, r);
-    int n = 0;
-    for (int base = lo; base < hi; base += 64) {
-        const int p = base + lane;
-        bool ok = false;
-        if (p < hi) {
-            const int iy = (int)(S.sorted[p] >> 16) % ORB_GRID_ROWS;
-            ok = iy >= w.y0 && iy < w.y1;
-            if (ok && checkLevels) {
-                const int o = S.oct[p];
-                if (o < minLevel) ok = false;
-                if (maxLevel >= 0 && o > maxLevel) ok = false;
-            }
-            if (ok) {
-                const float2 q = S.xy[p];
-                const float dx = __fsub_rn(q.x, x), dy = __fsub_rn(q.y, y);
-                ok = circ ? (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < r2) : (fabsf(dx) < r && fabsf(dy) < r);
-            }
-        }
-        const unsigned long long b = __ballot(ok);
-        if (ok) S.cand[n + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)p;
-        n += __popcll(b);
-    }
-    wave_lds_sync();
-    return n;
-}
 
 // Bucket range of GetFeaturesInArea(x, y, r), src/Frame.cc:91-112.
 static __device__ __forceinline__ Window window_cells(float x, float y, float r, float wInv, float hInv, bool excl) {
@@ -211,232 +161,481 @@ static __device__ void three_maxima(const int* histo, int& ind1, int& ind2, int&
     }
 }
 
-// SearchForInitialization for pair blockIdx.x.  binOf[i1] (global scratch, one
-// byte per first-frame keypoint) remembers the rotation bin a match was filed under.
-__global__ __launch_bounds__(64) void k_match_window(const orb_keypoint* __restrict__ k1all,
-                                                    const uint8_t* __restrict__ d1all, const int* __restrict__ n1s,
-                                                    int stride1, const orb_keypoint* __restrict__ k2all,
-                                                    const uint8_t* __restrict__ d2all, const int* __restrict__ n2s,
-                                                    int stride2, float imgW, float imgH, float* __restrict__ prevAll,
-                                                    int* __restrict__ m12All, uint8_t* __restrict__ binOfAll,
-                                                    float window, float nnratio, int checkOri, unsigned quirks,
-                                                    int* __restrict__ nmatchesOut, int* __restrict__ error) {
-    __shared__ MatchLds S;
-    const int pair = blockIdx.x, lane = threadIdx.x;
-    const orb_keypoint* k1 = k1all + (int64_t)pair * stride1;
-    const uint8_t* d1 = d1all + (int64_t)pair * stride1 * 32;
+// Device scratch of one call, per pair: the sorted grid of the searched frame and the per-query
+// candidate lists.
+struct MatchBuffers {
+    uint32_t* gSorted;   // [npairs][stride2]  bucket << 16 | keypoint index, ascending
+    float2* gXY;         // [npairs][stride2]  keypoint position by sorted position
+    uint8_t* gOct;       // [npairs][stride2]  keypoint octave by sorted position
+    int* cellStart;      // [npairs][M_CELLS + 1]
+    uint32_t* lists;     // [npairs][stride1][capQ]  distance << 16 | sorted position
+    int* counts;         // [npairs][stride1]
+    int* accepted;       // [npairs][stride1]  keypoint a query was matched to when it was resolved, -1 otherwise
+    int* order;          // [npairs][stride1]  queries with a non-empty list, ascending
+    int capQ;
+};
+
+// Kernel 1.  Bucket assignment as the Frame constructor does it (PosInGrid): rounded position,
+// keypoints that fall outside the grid are left out.
+__global__ __launch_bounds__(256) void k_grid_build(const orb_keypoint* __restrict__ k2all, const int* __restrict__ n2s,
+                                                    int n2const, int stride2, float imgW, float imgH, MatchBuffers B,
+                                                    int* __restrict__ error) {
+    __shared__ uint32_t s_sorted[M_MAXKP];
+    __shared__ uint32_t s_key[M_MAXKP];
+    __shared__ int s_start[M_CELLS + 1];
+    __shared__ int s_cursor[M_CELLS];
+    __shared__ int s_part[4];
+    __shared__ int s_big[M_MAXKP / 32];
+    __shared__ int s_nBig;
+    const int pair = blockIdx.x, t = threadIdx.x;
     const orb_keypoint* k2 = k2all + (int64_t)pair * stride2;
+    int* cellStart = B.cellStart + (int64_t)pair * (M_CELLS + 1);
+    const int n2 = n2s ? n2s[pair] : n2const;
+    if (n2 > stride2 || n2 > M_MAXKP || n2 < 0) {
+        if (t == 0) atomicOr(error, 1);
+        for (int c = t; c <= M_CELLS; c += 256) cellStart[c] = 0;  // an empty grid: the later kernels find nothing
+        return;
+    }
+    const float wInv = __fdiv_rn((float)ORB_GRID_COLS, imgW), hInv = __fdiv_rn((float)ORB_GRID_ROWS, imgH);
+    // Counting sort by bucket: histogram, prefix sum, scatter; a bucket's few entries are then put in
+    // index order by one thread (the scatter's order depends on how the atomics were served).
+    for (int c = t; c <= M_CELLS; c += 256) s_start[c] = 0;
+    __syncthreads();
+    for (int i = t; i < n2; i += 256) {
+        const int px = (int)roundf(__fmul_rn(k2[i].x, wInv));  // mnMinX = mnMinY = 0: no lens distortion
+        const int py = (int)roundf(__fmul_rn(k2[i].y, hInv));
+        uint32_t key = 0xFFFFFFFFu;
+        if (px >= 0 && px < ORB_GRID_COLS && py >= 0 && py < ORB_GRID_ROWS) {
+            key = ((uint32_t)(px * ORB_GRID_ROWS + py) << 16) | (uint32_t)i;
+            atomicAdd(&s_start[px * ORB_GRID_ROWS + py], 1);
+        }
+        s_key[i] = key;
+    }
+    __syncthreads();
+    {   // exclusive prefix sum of the M_CELLS counts: 12 consecutive buckets per thread, then across threads
+        const int per = M_CELLS / 256;  // 3072 / 256
+        int v[per], sum = 0;
+#pragma unroll
+        for (int j = 0; j < per; j++) {
+            v[j] = s_start[t * per + j];
+            sum += v[j];
+        }
+        const int lane = t & 63, wv = t >> 6;
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += u;
+        }
+        if (lane == 63) s_part[wv] = incl;
+        __syncthreads();
+        int run = incl - sum;
+        for (int w2 = 0; w2 < wv; w2++) run += s_part[w2];
+#pragma unroll
+        for (int j = 0; j < per; j++) {
+            s_start[t * per + j] = run;
+            s_cursor[t * per + j] = run;
+            run += v[j];
+        }
+        if (t == 255) s_start[M_CELLS] = run;
+    }
+    __syncthreads();
+    for (int i = t; i < n2; i += 256) {
+        const uint32_t key = s_key[i];
+        if (key != 0xFFFFFFFFu) s_sorted[atomicAdd(&s_cursor[key >> 16], 1)] = key;
+    }
+    __syncthreads();
+    if (t == 0) s_nBig = 0;
+    __syncthreads();
+    for (int c = t; c < M_CELLS; c += 256) {
+        const int lo = s_start[c], m = s_start[c + 1] - lo;
+        if (m > 32) {  // crowded bucket: left to the whole workgroup below (at most M_MAXKP / 32 of them)
+            s_big[atomicAdd(&s_nBig, 1)] = c;
+            continue;
+        }
+        for (int i = 1; i < m; i++) {
+            const uint32_t x = s_sorted[lo + i];
+            int j = i - 1;
+            while (j >= 0 && s_sorted[lo + j] > x) {
+                s_sorted[lo + j + 1] = s_sorted[lo + j];
+                j--;
+            }
+            s_sorted[lo + j + 1] = x;
+        }
+    }
+    __syncthreads();
+    for (int b = 0; b < s_nBig; b++) {  // rank sort through s_key, which is free again
+        const int lo = s_start[s_big[b]], m = s_start[s_big[b] + 1] - lo;
+        for (int i = t; i < m; i += 256) {
+            const uint32_t x = s_sorted[lo + i];
+            int r = 0;
+            for (int j = 0; j < m; j++) r += s_sorted[lo + j] < x;
+            s_key[r] = x;
+        }
+        __syncthreads();
+        for (int i = t; i < m; i += 256) s_sorted[lo + i] = s_key[i];
+        __syncthreads();
+    }
+    for (int c = t; c <= M_CELLS; c += 256) cellStart[c] = s_start[c];
+    __syncthreads();
+    const int nIn = s_start[M_CELLS];
+    uint32_t* gS = B.gSorted + (int64_t)pair * stride2;
+    float2* gXY = B.gXY + (int64_t)pair * stride2;
+    uint8_t* gO = B.gOct + (int64_t)pair * stride2;
+    for (int p = t; p < nIn; p += 256) {
+        const uint32_t key = s_sorted[p];
+        const orb_keypoint kp = k2[key & 0xFFFFu];
+        gS[p] = key;
+        gXY[p] = make_float2(kp.x, kp.y);
+        gO[p] = (uint8_t)(kp.octave < 0 ? 255 : (kp.octave > 254 ? 254 : kp.octave));
+    }
+}
+
+// Kernel 2.  PROJECTED = false: queries are the first frame's keypoints at octave 0, window centre
+// vbPrevMatched, fixed radius, level range [octave, octave] (src/ORBmatcher.cc:41-49).
+// PROJECTED = true: queries are projected map points with their own radius and level range (:323-336).
+template <bool PROJECTED>
+__global__ __launch_bounds__(256) void k_match_lists(const orb_keypoint* __restrict__ k1all,
+                                                     const uint8_t* __restrict__ d1all, const int* __restrict__ n1s,
+                                                     int nqConst, int stride1, const float* __restrict__ prevAll,
+                                                     float window, const float* __restrict__ u,
+                                                     const float* __restrict__ v, const float* __restrict__ radius,
+                                                     const int* __restrict__ minLevel, const int* __restrict__ maxLevel,
+                                                     const uint8_t* __restrict__ d2all, int stride2, float imgW,
+                                                     float imgH, unsigned quirks, MatchBuffers B) {
+    const int pair = blockIdx.y, lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nq = PROJECTED ? nqConst : n1s[pair];
+    if (q >= nq || q >= stride1) return;
+    int* counts = B.counts + (int64_t)pair * stride1;
+    float x, y, r;
+    int lmin, lmax;
+    bool active;
+    if (PROJECTED) {
+        x = u[q];
+        y = v[q];
+        r = radius[q];
+        lmin = minLevel[q];
+        lmax = maxLevel[q];
+        active = !(x < 0.f || x > imgW) && !(y < 0.f || y > imgH);  // :323-326
+    } else {
+        const orb_keypoint kp1 = k1all[(int64_t)pair * stride1 + q];
+        x = prevAll[((int64_t)pair * stride1 + q) * 2];
+        y = prevAll[((int64_t)pair * stride1 + q) * 2 + 1];
+        r = window;
+        lmin = lmax = kp1.octave;
+        active = !(kp1.octave > 0);  // :41-44
+    }
+    const bool excl = (quirks & ORB_Q_GRID_EXCLUSIVE) != 0, circ = (quirks & ORB_Q_WINDOW_CIRCULAR) != 0;
+    const float wInv = __fdiv_rn((float)ORB_GRID_COLS, imgW), hInv = __fdiv_rn((float)ORB_GRID_ROWS, imgH);
+    Window w;
+    w.x0 = w.x1 = w.y0 = w.y1 = 0;
+    if (active) w = window_cells(x, y, r, wInv, hInv, excl);
+    if (!active || w.x1 <= w.x0 || w.y1 <= w.y0) {
+        if (lane == 0) counts[q] = 0;
+        return;
+    }
+    const int* cellStart = B.cellStart + (int64_t)pair * (M_CELLS + 1);
+    const uint32_t* gS = B.gSorted + (int64_t)pair * stride2;
+    const float2* gXY = B.gXY + (int64_t)pair * stride2;
+    const uint8_t* gO = B.gOct + (int64_t)pair * stride2;
     const uint8_t* d2 = d2all + (int64_t)pair * stride2 * 32;
-    float* prev = prevAll + (int64_t)pair * stride1 * 2;
-    int* m12 = m12All + (int64_t)pair * stride1;
+    uint32_t* list = B.lists + ((int64_t)pair * stride1 + q) * B.capQ;
+    const int lo = cellStart[w.x0 * ORB_GRID_ROWS + w.y0];
+    const int hi = cellStart[(w.x1 - 1) * ORB_GRID_ROWS + w.y1];
+    const uint8_t* qd = d1all + ((int64_t)pair * stride1 + q) * 32;
+    const uint4 a0 = ((const uint4*)qd)[0], a1 = ((const uint4*)qd)[1];
+    const bool checkLevels = lmin >= 0 || lmax >= 0;
+    const float r2 = __fmul_rn(r, r);
+    int n = 0;
+    for (int base = lo; base < hi; base += 64) {
+        const int p = base + lane;
+        bool ok = false;
+        uint32_t key = 0;
+        if (p < hi) {
+            key = gS[p];
+            const int iy = (int)(key >> 16) % ORB_GRID_ROWS;
+            ok = iy >= w.y0 && iy < w.y1;
+            if (ok && checkLevels) {
+                const int o = gO[p];
+                if (o < lmin) ok = false;
+                if (lmax >= 0 && o > lmax) ok = false;
+            }
+            if (ok) {
+                const float2 c = gXY[p];
+                const float dx = __fsub_rn(c.x, x), dy = __fsub_rn(c.y, y);
+                ok = circ ? (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < r2) : (fabsf(dx) < r && fabsf(dy) < r);
+            }
+        }
+        const unsigned long long b = __ballot(ok);
+        if (ok) {
+            const uint32_t dist = (uint32_t)hamming_rows(a0, a1, d2 + (int64_t)(key & 0xFFFFu) * 32);
+            const int pos = n + __popcll(b & ((1ull << lane) - 1ull));
+            if (pos < B.capQ) list[pos] = (dist << 16) | (uint32_t)p;
+        }
+        n += __popcll(b);
+    }
+    if (lane == 0) counts[q] = n < B.capQ ? n : B.capQ;  // n <= keypoints in the grid <= capQ
+}
+
+// Kernel 3.
+struct ResolveLds {
+    uint32_t tile[2][64][128];      // first 128 list entries of 64 queries, double buffered
+    int metaI1[2][64];              // the 64 queries of a chunk: index, list length, "map point has observations"
+    int metaCnt[2][64];
+    int metaObs[2][64];
+    uint16_t idx[M_MAXKP];          // keypoint index by sorted position
+    // State of the searched frame's keypoints, by sorted position (the lists name positions).  Low half:
+    // vMatchedDistance (0xFFFF = INT_MAX) for the window search, occupancy flag for the projected one;
+    // high half: vnMatches21 (window search).
+    uint32_t so[M_MAXKP];
+    int hist[ORB_HISTO];
+    int wcount[4];
+    int nmatches;
+};
+
+template <bool PROJECTED>
+__global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __restrict__ k1all,
+                                                       const int* __restrict__ n1s, int nqConst, int stride1,
+                                                       const orb_keypoint* __restrict__ k2all,
+                                                       const int* __restrict__ n2s, int n2const, int stride2,
+                                                       float* __restrict__ prevAll, int* __restrict__ m12All,
+                                                       uint8_t* __restrict__ binOfAll, const float* __restrict__ qangle,
+                                                       const uint8_t* __restrict__ qobs,
+                                                       const uint8_t* __restrict__ occupied2, int* __restrict__ match2,
+                                                       float nnratio, int thHigh, int checkOri, MatchBuffers B,
+                                                       int* __restrict__ nmatchesOut, int* __restrict__ error) {
+    __shared__ ResolveLds S;
+    const int pair = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const orb_keypoint* k1 = PROJECTED ? nullptr : k1all + (int64_t)pair * stride1;
+    const orb_keypoint* k2 = k2all + (int64_t)pair * stride2;
+    float* prev = PROJECTED ? nullptr : prevAll + (int64_t)pair * stride1 * 2;
+    int* m12 = PROJECTED ? nullptr : m12All + (int64_t)pair * stride1;
     uint8_t* binOf = binOfAll + (int64_t)pair * stride1;
-    const int n1 = n1s[pair], n2 = n2s[pair];
-    if (n1 > stride1 || n2 > stride2 || n2 > M_MAXKP || n1 > 32767) {
-        if (lane == 0) {
+    const int* counts = B.counts + (int64_t)pair * stride1;
+    int* accepted = B.accepted + (int64_t)pair * stride1;
+    const uint32_t* lists = B.lists + (int64_t)pair * stride1 * B.capQ;
+    const int* cellStart = B.cellStart + (int64_t)pair * (M_CELLS + 1);
+    const uint32_t* gS = B.gSorted + (int64_t)pair * stride2;
+    const int nq = PROJECTED ? nqConst : n1s[pair];
+    const int n2 = n2s ? n2s[pair] : n2const;
+    if (nq > stride1 || nq > 32767 || n2 > stride2 || n2 > M_MAXKP) {
+        if (t == 0) {
             atomicOr(error, 1);
             nmatchesOut[pair] = 0;
         }
         return;
     }
-    const bool excl = (quirks & ORB_Q_GRID_EXCLUSIVE) != 0, circ = (quirks & ORB_Q_WINDOW_CIRCULAR) != 0;
-    const float wInv = __fdiv_rn((float)ORB_GRID_COLS, imgW), hInv = __fdiv_rn((float)ORB_GRID_ROWS, imgH);
-    for (int i = lane; i < n1; i += 64) {
-        m12[i] = -1;
+    const int nIn = cellStart[M_CELLS];
+    for (int i = t; i < nq; i += 256) {
+        if (!PROJECTED) m12[i] = -1;
         binOf[i] = 0xFF;
+        accepted[i] = -1;
     }
-    for (int i = lane; i < n2; i += 64) {
-        S.matchedDist[i] = 0xFFFF;
-        S.owner[i] = -1;
+    if (PROJECTED)
+        for (int i = t; i < n2; i += 256) match2[i] = -1;
+    for (int p = t; p < nIn; p += 256) {
+        const int i2 = (int)(gS[p] & 0xFFFFu);
+        S.idx[p] = (uint16_t)i2;
+        if (PROJECTED) S.so[p] = occupied2 ? occupied2[i2] : 0;
+        else S.so[p] = 0xFFFFFFFFu;  // distance INT_MAX, owner -1
     }
-    if (lane < ORB_HISTO) S.hist[lane] = 0;
-    int nIn = 0;
-    grid_build(S, k2, n2, wInv, hInv, lane, &nIn);
-    int nmatches = 0;
-    for (int i1 = 0; i1 < n1; i1++) {
-        const orb_keypoint kp1 = k1[i1];
-        if (kp1.octave > 0) continue;  // :41-44
-        const float x = prev[2 * i1], y = prev[2 * i1 + 1];
-        const Window w = window_cells(x, y, window, wInv, hInv, excl);
-        const uint4 a0 = ((const uint4*)(d1 + (int64_t)i1 * 32))[0], a1 = ((const uint4*)(d1 + (int64_t)i1 * 32))[1];
-        // per-lane running (distance << 16 | array position) minimum and second-smallest distance
-        uint32_t best = 0xFFFFFFFFu;
-        uint32_t second = 0xFFFFu;
-        const int nc = window_candidates(S, w, x, y, window, kp1.octave, kp1.octave, circ, lane);
-        for (int c = lane; c < nc; c += 64) {
-            const int p = S.cand[c];
-            const int i2 = (int)(S.sorted[p] & 0xFFFFu);
-            const uint32_t dist = (uint32_t)hamming_rows(a0, a1, d2 + (int64_t)i2 * 32);
-            if ((uint32_t)S.matchedDist[i2] <= dist) continue;  // :63-64
-            const uint32_t key = (dist << 16) | (uint32_t)p;
-            if (key < best) {
-                second = min(second, best >> 16);
-                best = key;
-            } else {
-                second = min(second, dist);
-            }
-        }
-        // wave reduction: smallest key; second = smallest distance among everything but that one entry
-        const uint32_t wbest = wave_min_u32(best);
-        const uint32_t cand2 = (best == wbest) ? second : min(second, best >> 16);
-        const uint32_t wsecond = wave_min_u32(cand2);
-        if (wbest == 0xFFFFFFFFu) continue;  // no candidate survived: bestDist = INT_MAX fails the TH_LOW test
-        const int bestDist = (int)(wbest >> 16);
-        const int bestIdx2 = (int)(S.sorted[wbest & 0xFFFFu] & 0xFFFFu);
-        const float bestDist2 = (wsecond == 0xFFFFu) ? (float)INT_MAX : (float)(int)wsecond;
-        if (bestDist <= M_TH_LOW && (float)bestDist < __fmul_rn(bestDist2, nnratio)) {  // :78-80
-            if (lane == 0) {
-                const int old = S.owner[bestIdx2];
-                if (old >= 0) {
-                    m12[old] = -1;
-                    nmatches--;
-                }
-                m12[i1] = bestIdx2;
-                S.owner[bestIdx2] = (int16_t)i1;
-                S.matchedDist[bestIdx2] = (uint16_t)bestDist;
-                nmatches++;
-                if (checkOri) {
-                    const int bin = rot_bin(kp1.angle, k2[bestIdx2].angle);
-                    binOf[i1] = (uint8_t)bin;
-                    S.hist[bin]++;
-                }
-            }
-            wave_lds_sync();
-        }
+    if (t < ORB_HISTO) S.hist[t] = 0;
+    if (t == 0) S.nmatches = 0;
+    __syncthreads();
+
+    // Queries with a non-empty list, in index order (the others cannot match and change nothing).
+    int* order = B.order + (int64_t)pair * stride1;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int nActive = 0;
+    for (int b0 = 0; b0 < nq; b0 += 256) {
+        const int i = b0 + t;
+        const bool act = i < nq && counts[i] > 0;
+        const unsigned long long m = __ballot(act);
+        if (lane == 0) S.wcount[wave] = __popcll(m);
+        __syncthreads();
+        int off = nActive;
+        for (int w2 = 0; w2 < wave; w2++) off += S.wcount[w2];
+        if (act) order[off + __popcll(m & below)] = i;
+        nActive += S.wcount[0] + S.wcount[1] + S.wcount[2] + S.wcount[3];
+        __syncthreads();
     }
     __threadfence_block();
-    wave_lds_sync();
-    nmatches = __shfl(nmatches, 0, 64);
-    if (checkOri) {
+    __syncthreads();
+
+    // Stages chunk `base` (64 consecutive active queries) into half `buf` of the tile: this wavefront
+    // takes queries qFirst, qFirst + qStep, ...; all of its loads are in flight at once.
+    auto stage = [&](int buf, int base, int qFirst, int qStep, bool meta) {
+        const int slot = base + lane;
+        const int i1L = slot < nActive ? order[slot] : -1;
+        const int cntL = i1L >= 0 ? counts[i1L] : 0;
+        if (meta) {
+            S.metaI1[buf][lane] = i1L;
+            S.metaCnt[buf][lane] = cntL;
+            S.metaObs[buf][lane] = (PROJECTED && qobs && i1L >= 0) ? qobs[i1L] : 1;
+        }
+        uint32_t e[22], f[22];
+#pragma unroll
+        for (int j = 0; j < 22; j++) {
+            const int qq = qFirst + j * qStep;
+            e[j] = f[j] = 0xFFFFFFFFu;
+            if (qq < 64) {
+                const int c = __shfl(cntL, qq, 64), i1 = __shfl(i1L, qq, 64);
+                if (lane < c) e[j] = lists[(int64_t)i1 * B.capQ + lane];
+                if (lane + 64 < c) f[j] = lists[(int64_t)i1 * B.capQ + lane + 64];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 22; j++) {
+            const int qq = qFirst + j * qStep;
+            if (qq < 64) {
+                S.tile[buf][qq][lane] = e[j];
+                S.tile[buf][qq][lane + 64] = f[j];
+            }
+        }
+    };
+
+    // Wavefront 0 resolves chunk k from one half of the tile while wavefronts 1-3 stage chunk k + 1
+    // into the other half.
+    int nmatches = 0;  // wave 0
+    const int nChunks = (nActive + 63) >> 6;
+    if (nChunks > 0) stage(0, 0, wave, 4, wave == 0);
+    __syncthreads();
+    for (int k = 0; k < nChunks; k++) {
+        const int base = k * 64, buf = k & 1;
+        if (wave != 0) {
+            if (k + 1 < nChunks) stage(buf ^ 1, base + 64, wave - 1, 3, wave == 1);
+        } else {
+            const int i1L = S.metaI1[buf][lane], cntL = S.metaCnt[buf][lane], obsL = S.metaObs[buf][lane];
+            const int nHere = nActive - base < 64 ? nActive - base : 64;
+            uint32_t e0 = S.tile[buf][0][lane], e1 = S.tile[buf][0][lane + 64];
+            for (int qq = 0; qq < nHere; qq++) {
+                const int i1 = __builtin_amdgcn_readlane(i1L, qq);
+                const int cnt = __builtin_amdgcn_readlane(cntL, qq);
+                const int obs = __builtin_amdgcn_readlane(obsL, qq);
+                // the next query's entries do not depend on this one's outcome: fetch them now
+                const int qn = qq + 1 < 64 ? qq + 1 : 63;
+                const uint32_t n0 = S.tile[buf][qn][lane], n1 = S.tile[buf][qn][lane + 64];
+                // this lane's two smallest surviving (distance << 16 | position) keys
+                uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+                auto consider = [&](uint32_t e) {
+                    const uint32_t st = S.so[e & 0xFFFFu] & 0xFFFFu;
+                    const bool skip = PROJECTED ? (st != 0) : (st <= (e >> 16));  // :345-347 / :63-64
+                    if (!skip) {
+                        k2 = min(k2, max(k1, e));
+                        k1 = min(k1, e);
+                    }
+                };
+                if (lane < cnt) consider(e0);
+                if (lane + 64 < cnt) consider(e1);
+                for (int c = lane + 128; c < cnt; c += 64) consider(lists[(int64_t)i1 * B.capQ + c]);
+                e0 = n0;
+                e1 = n1;
+                if (PROJECTED) k1 = wave_min_u32(k1);
+                else wave_top2_u32(k1, k2);
+                if (k1 == 0xFFFFFFFFu) continue;  // nothing survived: bestDist stays at its initial value and fails the test
+                const int bestDist = (int)(k1 >> 16);
+                const int bestPos = (int)(k1 & 0xFFFFu);
+                bool accept;
+                if (PROJECTED) {
+                    accept = bestDist < 256 && bestDist <= thHigh;  // bestDist starts at 256 with strict '<', :339,357,363
+                } else {
+                    // second best = smallest distance among everything but the winning entry
+                    const float bestDist2 = (k2 == 0xFFFFFFFFu) ? (float)INT_MAX : (float)(int)(k2 >> 16);
+                    accept = bestDist <= M_TH_LOW && (float)bestDist < __fmul_rn(bestDist2, nnratio);  // :78-80
+                }
+                if (accept) {
+                    const int bestIdx2 = S.idx[bestPos];
+                    const int old = (int)(int16_t)(S.so[bestPos] >> 16);
+                    if (lane == 0) {
+                        if (PROJECTED) {
+                            match2[bestIdx2] = i1;
+                            S.so[bestPos] = (uint32_t)obs;
+                        } else {
+                            if (old >= 0) {  // :82-86
+                                m12[old] = -1;
+                                nmatches--;
+                            }
+                            m12[i1] = bestIdx2;
+                            S.so[bestPos] = (uint32_t)bestDist | ((uint32_t)i1 << 16);
+                        }
+                        accepted[i1] = bestIdx2;
+                        nmatches++;
+                    }
+                    wave_lds_order();
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (t == 0) S.nmatches = nmatches;
+    __threadfence_block();
+    __syncthreads();
+    nmatches = S.nmatches;
+
+    if (checkOri) {  // :88-99 / :371-383 after the fact: one histogram entry per acceptance
+        for (int i = t; i < nq; i += 256) {
+            const int i2 = accepted[i];
+            if (i2 < 0) continue;
+            const int bin = rot_bin(PROJECTED ? qangle[i] : k1[i].angle, k2[i2].angle);
+            binOf[i] = (uint8_t)bin;
+            atomicAdd(&S.hist[bin], 1);
+        }
+        __syncthreads();
         int ind1, ind2, ind3;
         three_maxima(S.hist, ind1, ind2, ind3);
+        __syncthreads();
+        if (t == 0) S.nmatches = 0;
+        __syncthreads();
         int removed = 0;
-        for (int i = lane; i < n1; i += 64) {
+        for (int i = t; i < nq; i += 256) {
             const int bin = binOf[i];
             if (bin == 0xFF || bin == ind1 || bin == ind2 || bin == ind3) continue;
-            if (m12[i] >= 0) {  // :122-126 (a stolen match is already -1)
+            if (PROJECTED) {
+                match2[accepted[i]] = -2;  // :400-401, once per list entry (-2: assigned, then cleared)
+                removed++;
+            } else if (m12[i] >= 0) {  // :122-126 (a stolen match is already -1)
                 m12[i] = -1;
                 removed++;
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o, 64);
-        nmatches -= removed;
+        if (removed) atomicAdd(&S.nmatches, removed);
+        __syncthreads();
+        nmatches -= S.nmatches;
     }
-    __threadfence_block();
-    wave_lds_sync();
-    for (int i = lane; i < n1; i += 64) {  // :131-133
-        const int m = m12[i];
-        if (m >= 0) {
-            prev[2 * i] = k2[m].x;
-            prev[2 * i + 1] = k2[m].y;
-        }
-    }
-    if (lane == 0) nmatchesOut[pair] = nmatches;
-}
-
-// Search loop of SearchByProjection(Frame&, const Frame&, th, bMono) for one frame.
-__global__ __launch_bounds__(64) void k_match_projected(const float* __restrict__ u, const float* __restrict__ v,
-                                                       const float* __restrict__ radius,
-                                                       const int* __restrict__ minLevel,
-                                                       const int* __restrict__ maxLevel,
-                                                       const float* __restrict__ qangle,
-                                                       const uint8_t* __restrict__ qdesc,
-                                                       const uint8_t* __restrict__ qobs, int nq,
-                                                       const orb_keypoint* __restrict__ k2,
-                                                       const uint8_t* __restrict__ d2, int n2, float imgW, float imgH,
-                                                       const uint8_t* __restrict__ occupied2, int* __restrict__ match2,
-                                                       int* __restrict__ qBin, int* __restrict__ qIdx2, int thHigh,
-                                                       int checkOri, unsigned quirks, int* __restrict__ nmatchesOut,
-                                                       int* __restrict__ error) {
-    __shared__ MatchLds S;
-    const int lane = threadIdx.x;
-    if (n2 > M_MAXKP) {
-        if (lane == 0) {
-            atomicOr(error, 1);
-            nmatchesOut[0] = 0;
-        }
-        return;
-    }
-    const bool excl = (quirks & ORB_Q_GRID_EXCLUSIVE) != 0, circ = (quirks & ORB_Q_WINDOW_CIRCULAR) != 0;
-    const float wInv = __fdiv_rn((float)ORB_GRID_COLS, imgW), hInv = __fdiv_rn((float)ORB_GRID_ROWS, imgH);
-    for (int i = lane; i < n2; i += 64) {
-        match2[i] = -1;
-        S.matchedDist[i] = occupied2 ? occupied2[i] : 0;  // here: occupancy flag
-    }
-    for (int i = lane; i < nq; i += 64) qBin[i] = -1;
-    if (lane < ORB_HISTO) S.hist[lane] = 0;
-    int nIn = 0;
-    grid_build(S, k2, n2, wInv, hInv, lane, &nIn);
-    int nmatches = 0;
-    for (int i = 0; i < nq; i++) {
-        const float x = u[i], y = v[i];
-        if (x < 0.f || x > imgW) continue;  // :323-326
-        if (y < 0.f || y > imgH) continue;
-        const float r = radius[i];
-        const int lmin = minLevel[i], lmax = maxLevel[i];
-        const Window w = window_cells(x, y, r, wInv, hInv, excl);
-        const uint4 a0 = ((const uint4*)(qdesc + (int64_t)i * 32))[0], a1 = ((const uint4*)(qdesc + (int64_t)i * 32))[1];
-        uint32_t best = 0xFFFFFFFFu;
-        const int nc = window_candidates(S, w, x, y, r, lmin, lmax, circ, lane);
-        for (int c = lane; c < nc; c += 64) {
-            const int p = S.cand[c];
-            const int i2 = (int)(S.sorted[p] & 0xFFFFu);
-            if (S.matchedDist[i2]) continue;  // :345-347
-            const uint32_t dist = (uint32_t)hamming_rows(a0, a1, d2 + (int64_t)i2 * 32);
-            best = min(best, (dist << 16) | (uint32_t)p);
-        }
-        const uint32_t wbest = wave_min_u32(best);
-        if (wbest == 0xFFFFFFFFu) continue;
-        const int bestDist = (int)(wbest >> 16);
-        if (bestDist >= 256) continue;  // bestDist starts at 256 with strict '<', :339,357
-        if (bestDist <= thHigh) {
-            const int bestIdx2 = (int)(S.sorted[wbest & 0xFFFFu] & 0xFFFFu);
-            if (lane == 0) {
-                match2[bestIdx2] = i;
-                S.matchedDist[bestIdx2] = qobs ? qobs[i] : 1;
-                nmatches++;
-                if (checkOri) {
-                    const int bin = rot_bin(qangle[i], k2[bestIdx2].angle);
-                    qBin[i] = bin;
-                    qIdx2[i] = bestIdx2;
-                    S.hist[bin]++;
-                }
+    if (!PROJECTED) {
+        __threadfence_block();
+        __syncthreads();
+        for (int i = t; i < nq; i += 256) {  // :131-133
+            const int m = m12[i];
+            if (m >= 0) {
+                prev[2 * i] = k2[m].x;
+                prev[2 * i + 1] = k2[m].y;
             }
-            wave_lds_sync();
         }
     }
-    __threadfence_block();
-    wave_lds_sync();
-    nmatches = __shfl(nmatches, 0, 64);
-    if (checkOri) {
-        int ind1, ind2, ind3;
-        three_maxima(S.hist, ind1, ind2, ind3);
-        int removed = 0;
-        for (int i = lane; i < nq; i += 64) {
-            const int bin = qBin[i];
-            if (bin < 0 || bin == ind1 || bin == ind2 || bin == ind3) continue;
-            match2[qIdx2[i]] = -2;  // :400-401, once per list entry (-2: assigned, then cleared)
-            removed++;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) removed += __shfl_xor(removed, o, 64);
-        nmatches -= removed;
-    }
-    if (lane == 0) nmatchesOut[0] = nmatches;
+    if (t == 0) nmatchesOut[pair] = nmatches;
 }
 
 // ---- host side ------------------------------------------------------------------------
 struct MatchState {
-    void* binOf = nullptr;
-    size_t binBytes = 0;
     void* err = nullptr;
+    // scratch, grown on demand and kept
+    void* gSorted = nullptr; void* gXY = nullptr; void* gOct = nullptr; void* cellStart = nullptr;
+    void* lists = nullptr; void* counts = nullptr; void* accepted = nullptr; void* order = nullptr;
+    void* binOf = nullptr;
+    size_t capPairs2 = 0;   // npairs * stride2 the grid arrays hold
+    size_t capPairs = 0;    // pairs cellStart holds
+    size_t capPairs1 = 0;   // npairs * stride1 the per-query arrays hold
+    size_t capLists = 0;    // list entries
 };
 
 void orb_match_state_free(void* p) {
     MatchState* s = (MatchState*)p;
     if (!s) return;
-    if (s->binOf) (void)hipFree(s->binOf);
-    if (s->err) (void)hipFree(s->err);
+    void* bufs[] = {s->err, s->gSorted, s->gXY, s->gOct, s->cellStart, s->lists, s->counts, s->accepted, s->order, s->binOf};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
     delete s;
 }
 
@@ -445,9 +644,24 @@ int orb_ctx_device(const orb_ctx* c);
 unsigned orb_ctx_quirks(const orb_ctx* c);
 int orb_ctx_max_batch(const orb_ctx* c);
 void** orb_ctx_match_state(orb_ctx* c);
-void* orb_ctx_stream(orb_ctx* c);
 
-static int match_state(orb_ctx* c, size_t binBytes, MatchState** out) {
+static int grow(void** p, size_t bytes) {
+    if (*p) {
+        HIP_TRY(hipDeviceSynchronize());  // earlier launches may still use the old buffer
+        (void)hipFree(*p);
+        *p = nullptr;
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        *p = nullptr;
+        orb_set_error("matcher scratch: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return ORB_ERR_NOMEM;
+    }
+    return ORB_OK;
+}
+
+// Makes the scratch large enough for npairs pairs of (stride1 queries, stride2 searched keypoints).
+static int match_buffers(orb_ctx* c, int npairs, int stride1, int stride2, MatchState** out, MatchBuffers* B) {
     void** slot = orb_ctx_match_state(c);
     if (!*slot) {
         MatchState* s = new MatchState();
@@ -461,18 +675,54 @@ static int match_state(orb_ctx* c, size_t binBytes, MatchState** out) {
         *slot = s;
     }
     MatchState* s = (MatchState*)*slot;
-    if (binBytes > s->binBytes) {
-        if (s->binOf) (void)hipFree(s->binOf);
-        s->binOf = nullptr;
-        s->binBytes = 0;
-        hipError_t e = hipMalloc(&s->binOf, binBytes);
-        if (e != hipSuccess) {
-            orb_set_error("hipMalloc(%zu) failed: %s", binBytes, hipGetErrorString(e));
-            return ORB_ERR_NOMEM;
-        }
-        s->binBytes = binBytes;
+    int rc;
+    const size_t p2 = (size_t)npairs * stride2, p1 = (size_t)npairs * stride1;
+    const int capQ = stride2;  // a window can hold every keypoint of the searched frame
+    const size_t nl = p1 * (size_t)capQ;
+    if (p2 > s->capPairs2) {
+        s->capPairs2 = 0;
+        if ((rc = grow(&s->gSorted, p2 * 4))) return rc;
+        if ((rc = grow(&s->gXY, p2 * 8))) return rc;
+        if ((rc = grow(&s->gOct, p2))) return rc;
+        s->capPairs2 = p2;
     }
+    if ((size_t)npairs > s->capPairs) {
+        s->capPairs = 0;
+        if ((rc = grow(&s->cellStart, (size_t)npairs * (M_CELLS + 1) * 4))) return rc;
+        s->capPairs = npairs;
+    }
+    if (p1 > s->capPairs1) {
+        s->capPairs1 = 0;
+        if ((rc = grow(&s->counts, p1 * 4))) return rc;
+        if ((rc = grow(&s->accepted, p1 * 4))) return rc;
+        if ((rc = grow(&s->order, p1 * 4))) return rc;
+        if ((rc = grow(&s->binOf, p1))) return rc;
+        s->capPairs1 = p1;
+    }
+    if (nl > s->capLists) {
+        s->capLists = 0;
+        if ((rc = grow(&s->lists, nl * 4))) return rc;
+        s->capLists = nl;
+    }
+    B->gSorted = (uint32_t*)s->gSorted;
+    B->gXY = (float2*)s->gXY;
+    B->gOct = (uint8_t*)s->gOct;
+    B->cellStart = (int*)s->cellStart;
+    B->lists = (uint32_t*)s->lists;
+    B->counts = (int*)s->counts;
+    B->accepted = (int*)s->accepted;
+    B->order = (int*)s->order;
+    B->capQ = capQ;
     *out = s;
+    return ORB_OK;
+}
+
+static int check_match_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        orb_set_error("match launch failed: %s", hipGetErrorString(e));
+        return ORB_ERR_HIP;
+    }
     return ORB_OK;
 }
 
@@ -497,17 +747,23 @@ extern "C" int orb_match_window_batch_device(orb_ctx* c, int npairs, const orb_k
     }
     HIP_TRY(hipSetDevice(orb_ctx_device(c)));
     MatchState* s = nullptr;
-    int rc = match_state(c, (size_t)orb_ctx_max_batch(c) * 32768, &s);
+    MatchBuffers B;
+    int rc = match_buffers(c, npairs, stride1, stride2, &s, &B);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_match_window, dim3(npairs), dim3(64), 0, (hipStream_t)stream, d_k1, d_d1, d_n1, stride1, d_k2,
-                       d_d2, d_n2, stride2, (float)img_w, (float)img_h, d_prev_xy, d_matches12, (uint8_t*)s->binOf,
-                       (float)window, nnratio, check_ori, orb_ctx_quirks(c), d_nmatches, (int*)s->err);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
-        orb_set_error("match launch failed: %s", hipGetErrorString(e));
-        return ORB_ERR_HIP;
-    }
-    return ORB_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(256), 0, st, d_k2, d_n2, 0, stride2, (float)img_w, (float)img_h, B,
+                       (int*)s->err);
+    if ((rc = check_match_launch())) return rc;
+    hipLaunchKernelGGL(k_match_lists<false>, dim3((stride1 + 3) / 4, npairs), dim3(256), 0, st, d_k1, d_d1, d_n1, 0,
+                       stride1, (const float*)d_prev_xy, (float)window, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const int*)nullptr, (const int*)nullptr, d_d2, stride2, (float)img_w,
+                       (float)img_h, orb_ctx_quirks(c), B);
+    if ((rc = check_match_launch())) return rc;
+    hipLaunchKernelGGL(k_match_resolve<false>, dim3(npairs), dim3(256), 0, st, d_k1, d_n1, 0, stride1, d_k2, d_n2, 0,
+                       stride2, d_prev_xy, d_matches12, (uint8_t*)s->binOf, (const float*)nullptr,
+                       (const uint8_t*)nullptr, (const uint8_t*)nullptr, (int*)nullptr, nnratio, 0, check_ori, B,
+                       d_nmatches, (int*)s->err);
+    return check_match_launch();
 }
 
 namespace {
@@ -523,6 +779,17 @@ struct Tmp {  // scoped device allocation for the host-pointer entry points
     }
 };
 }  // namespace
+
+static int read_match_error(MatchState* s, const char* what) {
+    int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, s->err, 4, hipMemcpyDeviceToHost));
+    if (flag) {
+        HIP_TRY(hipMemset(s->err, 0, 4));
+        orb_set_error("%s: keypoint count exceeds the kernel's limits", what);
+        return ORB_ERR_CAPACITY;
+    }
+    return ORB_OK;
+}
 
 extern "C" int orb_match_window(orb_ctx* c, const orb_keypoint* k1, const uint8_t* d1, int n1, const orb_keypoint* k2,
                                 const uint8_t* d2, int n2, int img_w, int img_h, float* prev_xy, int* matches12,
@@ -552,14 +819,7 @@ extern "C" int orb_match_window(orb_ctx* c, const orb_keypoint* k1, const uint8_
                                            (int*)tnm.p, nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
-    MatchState* s = (MatchState*)*orb_ctx_match_state(c);
-    int flag = 0;
-    HIP_TRY(hipMemcpy(&flag, s->err, 4, hipMemcpyDeviceToHost));
-    if (flag) {
-        HIP_TRY(hipMemset(s->err, 0, 4));
-        orb_set_error("windowed matcher: keypoint count exceeds the kernel's limits");
-        return ORB_ERR_CAPACITY;
-    }
+    if ((rc = read_match_error((MatchState*)*orb_ctx_match_state(c), "windowed matcher"))) return rc;
     HIP_TRY(hipMemcpy(prev_xy, tprev.p, (size_t)n1 * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(matches12, tm.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(nmatches, tnm.p, 4, hipMemcpyDeviceToHost));
@@ -577,16 +837,21 @@ extern "C" int orb_match_projected(orb_ctx* c, const float* u, const float* v, c
         return ORB_ERR_INVALID;
     }
     *nmatches = 0;
-    if (n2 > M_MAXKP) {
-        orb_set_error("projected matcher handles at most %d keypoints in the searched frame", M_MAXKP);
+    if (n2 > M_MAXKP || nq > 32767) {
+        orb_set_error("projected matcher handles at most %d keypoints in the searched frame and 32767 queries", M_MAXKP);
         return ORB_ERR_UNSUPPORTED;
     }
     if (n2 == 0) return ORB_OK;
+    if (nq == 0) {
+        for (int i = 0; i < n2; i++) match2[i] = -1;
+        return ORB_OK;
+    }
     HIP_TRY(hipSetDevice(orb_ctx_device(c)));
     MatchState* s = nullptr;
-    int rc = match_state(c, 4, &s);
+    MatchBuffers B;
+    int rc = match_buffers(c, 1, nq, n2, &s, &B);
     if (rc) return rc;
-    Tmp tu, tv, tr, tl0, tl1, ta, tq, to, tk2, td2, tocc, tm, tb, ti, tnm;
+    Tmp tu, tv, tr, tl0, tl1, ta, tq, to, tk2, td2, tocc, tm, tnm;
     HIP_TRY(tu.put(u, (size_t)nq * 4));
     HIP_TRY(tv.put(v, (size_t)nq * 4));
     HIP_TRY(tr.put(radius, (size_t)nq * 4));
@@ -599,20 +864,23 @@ extern "C" int orb_match_projected(orb_ctx* c, const float* u, const float* v, c
     HIP_TRY(td2.put(d2, (size_t)n2 * 32));
     if (occupied2) HIP_TRY(tocc.put(occupied2, (size_t)n2));
     HIP_TRY(tm.put(nullptr, (size_t)n2 * 4));
-    HIP_TRY(tb.put(nullptr, (size_t)nq * 4));
-    HIP_TRY(ti.put(nullptr, (size_t)nq * 4));
     HIP_TRY(tnm.put(nullptr, 4));
-    hipLaunchKernelGGL(k_match_projected, dim3(1), dim3(64), 0, (hipStream_t) nullptr, (const float*)tu.p,
+    hipStream_t st = nullptr;
+    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, st, (const orb_keypoint*)tk2.p, (const int*)nullptr, n2, n2,
+                       (float)img_w, (float)img_h, B, (int*)s->err);
+    if ((rc = check_match_launch())) return rc;
+    hipLaunchKernelGGL(k_match_lists<true>, dim3((nq + 3) / 4, 1), dim3(256), 0, st, (const orb_keypoint*)nullptr,
+                       (const uint8_t*)tq.p, (const int*)nullptr, nq, nq, (const float*)nullptr, 0.f, (const float*)tu.p,
                        (const float*)tv.p, (const float*)tr.p, (const int*)tl0.p, (const int*)tl1.p,
-                       (const float*)ta.p, (const uint8_t*)tq.p, (const uint8_t*)to.p, nq, (const orb_keypoint*)tk2.p,
-                       (const uint8_t*)td2.p, n2, (float)img_w, (float)img_h, (const uint8_t*)tocc.p, (int*)tm.p,
-                       (int*)tb.p, (int*)ti.p, th_high, check_ori, orb_ctx_quirks(c), (int*)tnm.p, (int*)s->err);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
-        orb_set_error("match launch failed: %s", hipGetErrorString(e));
-        return ORB_ERR_HIP;
-    }
+                       (const uint8_t*)td2.p, n2, (float)img_w, (float)img_h, orb_ctx_quirks(c), B);
+    if ((rc = check_match_launch())) return rc;
+    hipLaunchKernelGGL(k_match_resolve<true>, dim3(1), dim3(256), 0, st, (const orb_keypoint*)nullptr,
+                       (const int*)nullptr, nq, nq, (const orb_keypoint*)tk2.p, (const int*)nullptr, n2, n2,
+                       (float*)nullptr, (int*)nullptr, (uint8_t*)s->binOf, (const float*)ta.p, (const uint8_t*)to.p,
+                       (const uint8_t*)tocc.p, (int*)tm.p, 0.f, th_high, check_ori, B, (int*)tnm.p, (int*)s->err);
+    if ((rc = check_match_launch())) return rc;
     HIP_TRY(hipDeviceSynchronize());
+    if ((rc = read_match_error(s, "projected matcher"))) return rc;
     HIP_TRY(hipMemcpy(match2, tm.p, (size_t)n2 * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(nmatches, tnm.p, 4, hipMemcpyDeviceToHost));
     return ORB_OK;
