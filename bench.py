@@ -264,6 +264,27 @@ def main():
             tc = time.perf_counter() - t0
             cpu = {"value": round(reps / tc, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                    "sample": "%d frames of the same batch, single thread (the reference extracts on one tracking thread)" % reps}
+            # the same port with one extractor per host thread (ctypes releases the GIL inside the call)
+            import threading
+
+            nthr = max(1, min(16, os.cpu_count() or 1))
+            per = max(4, args.cpu_frames // 4)
+            exts = [oracle.Extractor(args.nfeatures, 1.2, 8, 20, 7, oracle.QUIRKS_FORK if args.preset == "fork" else oracle.QUIRKS_CANONICAL)
+                    for _ in range(nthr)]
+
+            def work(k):
+                for i in range(per):
+                    exts[k].extract(frames[(k * per + i) % nc])
+
+            th = [threading.Thread(target=work, args=(k,)) for k in range(nthr)]
+            t0 = time.perf_counter()
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            tm = time.perf_counter() - t0
+            cpu["all_cores"] = {"value": round(nthr * per / tm, 3), "unit": "frames/s", "cores": nthr,
+                                "sample": "%d frames per thread, one extractor per thread" % per}
 
     if rank == 0:
         out = {
