@@ -164,6 +164,24 @@ int orb_match_projected(orb_ctx* ctx, const float* u, const float* v, const floa
                         const orb_keypoint* k2, const uint8_t* d2, int n2, int img_w, int img_h,
                         const uint8_t* occupied2, int* match2, int th_high, int check_ori, int* nmatches);
 
+/* MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:158-222, for npoints
+ * map points at once.  desc holds every point's observation descriptors back
+ * to back (32 bytes each), point p owning rows offsets[p] .. offsets[p+1]-1 in
+ * the order the reference collects them (:176-181).  best_index[p] = row,
+ * within the point's list, of the descriptor with the least median distance
+ * to the others (first on ties, :208-212), -1 for an empty list (the reference
+ * returns without touching mDescriptor); best_median (may be NULL) receives
+ * that median.  self_distance != 0 reproduces the fork's line :195, which
+ * compares every descriptor with itself (all distances 0, row 0 wins);
+ * 0 is upstream ORB-SLAM2 (descriptor i against descriptor j).  Lists of up to
+ * 65535 observations. */
+int orb_distinctive_descriptors(orb_ctx* ctx, const uint8_t* desc, const int* offsets, int npoints, int self_distance,
+                                int* best_index, int* best_median);
+/* The same on device-resident arrays (d_desc 4-byte aligned); a list longer
+ * than 65535 yields best_index -2. */
+int orb_distinctive_descriptors_device(orb_ctx* ctx, const uint8_t* d_desc, const int* d_offsets, int npoints,
+                                       int self_distance, int* d_best_index, int* d_best_median, void* stream);
+
 /* ---- brute-force top-2 (relocalisation / loop-candidate scale) ----------- */
 
 /* Dense scan with the best / second-best rule of src/ORBmatcher.cc:53-76:

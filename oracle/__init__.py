@@ -232,3 +232,12 @@ def bf_top2(q, db):
     d2 = np.zeros(nq, dtype=np.uint16)
     lib().oro_bf_top2(_p(q), nq, _p(db), C.c_longlong(nd), _p(idx), _p(d1), _p(d2))
     return idx, d1, d2
+
+
+def distinctive_descriptor(desc, self_distance=False):
+    """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:186-214) on an (n, 32) uint8 array:
+    (index of the chosen descriptor, its median distance); (-1, None) for n == 0."""
+    desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 32)
+    med = C.c_int(0)
+    i = lib().oro_distinctive(_p(desc), len(desc), int(self_distance), C.byref(med))
+    return (i, med.value) if i >= 0 else (-1, None)

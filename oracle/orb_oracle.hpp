@@ -114,6 +114,11 @@ int searchByProjection(const float* u, const float* v, const float* radius, cons
                        const uint8_t* occupied2, int* match2 /*n2, -1 or query idx*/, int thHigh, bool checkOri,
                        unsigned quirks);
 
+// MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:186-214: index of the descriptor with the least median
+// distance to the others (first on ties); *median receives that median.  selfDistance reproduces the fork's
+// DescriptorDistance(d[i], d[i]) at :195 (every distance 0).  Returns -1 for n == 0.
+int distinctiveDescriptor(const uint8_t* desc, int n, bool selfDistance, int* median);
+
 void bruteForceTop2(const uint8_t* q, int nq, const uint8_t* db, int64_t nd, int32_t* bestIdx, uint16_t* bestDist,
                     uint16_t* secondDist);
 

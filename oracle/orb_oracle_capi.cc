@@ -175,4 +175,8 @@ void oro_bf_top2(const uint8_t* q, int nq, const uint8_t* db, long long nd, int3
     bruteForceTop2(q, nq, db, nd, idx, d1, d2);
 }
 
+int oro_distinctive(const uint8_t* desc, int n, int selfDistance, int* median) {
+    return distinctiveDescriptor(desc, n, selfDistance != 0, median);
+}
+
 }  // extern "C"

@@ -293,4 +293,31 @@ void bruteForceTop2(const uint8_t* q, int nq, const uint8_t* db, int64_t nd, int
     }
 }
 
+// src/MapPoint.cc:186-214.  Distances are kept as float and sorted as int, as the reference does.
+int distinctiveDescriptor(const uint8_t* desc, int n, bool selfDistance, int* median) {
+    if (n <= 0) return -1;
+    const std::size_t N = (std::size_t)n;
+    std::vector<std::vector<float>> Distances(N, std::vector<float>(N, 0));
+    for (std::size_t i = 0; i < N; i++) {
+        Distances[i][i] = 0;
+        for (std::size_t j = i + 1; j < N; j++) {
+            const int distij = hammingBitHack(desc + 32 * i, desc + 32 * (selfDistance ? i : j));  // :195
+            Distances[i][j] = (float)distij;
+            Distances[j][i] = (float)distij;
+        }
+    }
+    int BestMedian = INT_MAX, BestIdx = 0;
+    for (std::size_t i = 0; i < N; i++) {
+        std::vector<int> vDists(Distances[i].begin(), Distances[i].end());
+        std::sort(vDists.begin(), vDists.end());
+        const int med = vDists[(std::size_t)(0.5 * (N - 1))];
+        if (med < BestMedian) {
+            BestMedian = med;
+            BestIdx = (int)i;
+        }
+    }
+    if (median) *median = BestMedian;
+    return BestIdx;
+}
+
 }  // namespace orbo

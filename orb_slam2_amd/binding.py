@@ -30,6 +30,7 @@ EXPORTS = [
     "orb_match_window_batch_device", "orb_match_projected", "orb_bf_create", "orb_bf_destroy", "orb_bf_set_database",
     "orb_bf_set_database_device", "orb_bf_query_top2", "orb_bf_query_packed_device", "orb_bf_merge_packed_device",
     "orb_enable_stage_timing", "orb_get_stage_timings", "orb_last_error", "orb_version",
+    "orb_distinctive_descriptors", "orb_distinctive_descriptors_device",
 ]
 
 
@@ -236,6 +237,22 @@ class Context:
                                          _p(qdesc), _p(qobs), len(u), _p(k2), _p(d2), len(k2), img_w, img_h, _p(occ),
                                          _p(match2), th_high, int(check_ori), C.byref(nm)))
         return nm.value, match2[: len(k2)]
+
+    def distinctive_descriptors(self, desc, offsets, self_distance=False):
+        """MapPoint::ComputeDistinctiveDescriptors for the map points whose observation descriptors are
+        desc[offsets[p]:offsets[p+1]].  Returns (best_index, best_median) int32 arrays."""
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        offsets = np.ascontiguousarray(offsets, np.int32)
+        npts = len(offsets) - 1
+        best = np.zeros(max(npts, 1), np.int32)
+        med = np.zeros(max(npts, 1), np.int32)
+        _check(lib().orb_distinctive_descriptors(self.h, _p(desc), _p(offsets), npts, int(self_distance), _p(best), _p(med)))
+        return best[:npts], med[:npts]
+
+    def distinctive_descriptors_device(self, d_desc, d_offsets, d_best, d_median=None, self_distance=False, stream=None):
+        _check(lib().orb_distinctive_descriptors_device(self.h, _dp(d_desc), _dp(d_offsets), d_offsets.shape[0] - 1,
+                                                        int(self_distance), _dp(d_best),
+                                                        _dp(d_median) if d_median is not None else None, _stream(stream)))
 
 
 class BruteForce:

@@ -139,4 +139,7 @@ int orb_launch_resize_single(const uint8_t* d_src, int sw, int sh, int sstride, 
 int orb_launch_blur_single(const uint8_t* d_src, int w, int h, int sstride, uint8_t* d_dst, int dstride, int legacy,
                            void* stream);
 
+int orb_launch_distinctive(const uint8_t* d_desc, const int* d_offsets, int npoints, int selfDistance, int* d_best,
+                           int* d_median, void* stream);
+
 void orb_set_error(const char* fmt, ...);

@@ -336,6 +336,47 @@ def test_brute_force_sharded_merge(hip, oracle):
             bf.close()
 
 
+def test_distinctive_descriptors(hip, oracle):
+    """MapPoint::ComputeDistinctiveDescriptors batched: ragged lists incl. empty, 1, 2, 64, 65, > LDS capacity,
+    near-duplicate descriptors (many ties), both the fork's self-comparison and upstream behaviour."""
+    c = _ctx(hip, "fork")
+    sizes = [0, 1, 2, 3, 4, 7, 16, 63, 64, 65, 130, 600, 0, 5, 33]
+    base = synth_descriptors(64, 0xD15C)
+    lists = []
+    for k, n in enumerate(sizes):
+        r = splitmix64(77 + k, max(n, 1) * 4).reshape(-1, 4)
+        rows = []
+        for i in range(n):
+            v = base[int(r[i, 0] % np.uint64(8))].copy()            # a few clusters -> many equal medians
+            nflip = int(r[i, 1] % np.uint64(40))
+            bits = splitmix64(int(r[i, 2] & np.uint64(0xFFFFFFFF)), max(nflip, 1)) % np.uint64(256)
+            for b in bits[:nflip]:
+                v[int(b) // 8] ^= np.uint8(1 << (int(b) % 8))
+            rows.append(v)
+        lists.append(np.stack(rows) if rows else np.zeros((0, 32), np.uint8))
+    desc = np.concatenate(lists)
+    offsets = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int32)
+    for self_distance in (False, True):
+        best, med = c.distinctive_descriptors(desc, offsets, self_distance)
+        for p, rows in enumerate(lists):
+            ri, rm = oracle.distinctive_descriptor(rows, self_distance)
+            assert best[p] == ri, "point %d (n=%d, self=%s): index %d, oracle %d" % (p, len(rows), self_distance, best[p], ri)
+            if ri >= 0:
+                assert med[p] == rm, "point %d: median %d, oracle %d" % (p, med[p], rm)
+    # device entry point
+    import torch
+
+    d_desc = torch.from_numpy(desc).cuda()
+    d_off = torch.from_numpy(offsets).cuda()
+    d_best = torch.zeros(len(sizes), dtype=torch.int32, device="cuda")
+    d_med = torch.zeros(len(sizes), dtype=torch.int32, device="cuda")
+    c.distinctive_descriptors_device(d_desc, d_off, d_best, d_med)
+    torch.cuda.synchronize()
+    best, _ = c.distinctive_descriptors(desc, offsets, False)
+    np.testing.assert_array_equal(d_best.cpu().numpy(), best)
+    c.close()
+
+
 def test_extract_4k_frame(hip, oracle):
     """Config-4 shape: one 3840x2160 frame, 4000 features (about 130k FAST keys on level 0)."""
     w, h, nf = 3840, 2160, 4000

@@ -200,3 +200,29 @@ def test_brute_force_top2_ties(oracle):
     idx, d1, d2 = oracle.bf_top2(q, db)
     assert idx[0] == 10 and d1[0] == 0 and d2[0] == 0  # tie for best: second == best, lower index wins
     assert idx[1] == 20 and d1[1] == 0 and d2[1] > 0
+
+
+def test_distinctive_descriptor_known_answers(oracle):
+    """MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:186-214) on cases worked by hand."""
+    z = np.zeros(32, np.uint8)
+
+    def d(nbits):  # descriptor with the lowest `nbits` bits set: distance to z is nbits
+        v = np.zeros(32, np.uint8)
+        v[: nbits // 8] = 255
+        if nbits % 8:
+            v[nbits // 8] = (1 << (nbits % 8)) - 1
+        return v
+
+    # one observation: itself, median 0
+    assert oracle.distinctive_descriptor(np.stack([d(9)])) == (0, 0)
+    # two observations: rows {0, 9} and {9, 0}; k = (size_t)(0.5 * 1) = 0 -> both medians 0, first wins
+    assert oracle.distinctive_descriptor(np.stack([z, d(9)])) == (0, 0)
+    # three: distances z-d(4) = 4, z-d(10) = 10, d(4)-d(10) = 6; sorted rows {0,4,10} {0,4,6} {0,6,10}, k = 1:
+    # medians 4, 4, 6 -> row 0 (strict '<' keeps the first)
+    assert oracle.distinctive_descriptor(np.stack([z, d(4), d(10)])) == (0, 4)
+    # four: k = (size_t)1.5 = 1; rows of d(0), d(8), d(10), d(40): {0,8,10,40} {0,2,8,32} {0,2,10,30} {0,30,32,40}
+    # medians 8, 2, 2, 30 -> row 1
+    assert oracle.distinctive_descriptor(np.stack([z, d(8), d(10), d(40)])) == (1, 2)
+    # the fork's self-comparison at :195 makes every distance 0
+    assert oracle.distinctive_descriptor(np.stack([d(40), d(8), z]), self_distance=True) == (0, 0)
+    assert oracle.distinctive_descriptor(np.zeros((0, 32), np.uint8)) == (-1, None)
