@@ -5,6 +5,8 @@
 //
 // usage: orb_demo <in.bin> <out.bin>
 //   in.bin : int32 w, h, nfeatures, window; float nnratio; then 2 * w*h bytes (frame A, frame B)
+//   environment ORBDEMO_CAMERA="fx,fy,cx,cy,k1,k2,p1,p2,k3" replaces the default pinhole camera
+//   (fx = fy = 500, principal point at the image centre, no distortion)
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -38,6 +40,13 @@ int main(int argc, char** argv) {
         K.at<float>(0, 0) = 500.f; K.at<float>(1, 1) = 500.f; K.at<float>(0, 2) = w / 2.f; K.at<float>(1, 2) = h / 2.f;
         K.at<float>(2, 2) = 1.f;
         for (int i = 0; i < 4; i++) dist.at<float>(i) = 0.f;
+        if (const char* cam = getenv("ORBDEMO_CAMERA")) {
+            float c[9] = {0};
+            if (sscanf(cam, "%f,%f,%f,%f,%f,%f,%f,%f,%f", &c[0], &c[1], &c[2], &c[3], &c[4], &c[5], &c[6], &c[7], &c[8]) != 9) return 7;
+            K.at<float>(0, 0) = c[0]; K.at<float>(1, 1) = c[1]; K.at<float>(0, 2) = c[2]; K.at<float>(1, 2) = c[3];
+            dist = cv::Mat(c[8] != 0.f ? 5 : 4, 1, CV_32F);  // src/Tracking.cc:76-88: k3 only when non-zero
+            for (int i = 0; i < dist.rows; i++) dist.at<float>(i) = c[4 + i];
+        }
         Frame F1(imA, 0.0, &ext, nullptr, K, dist, 40.f, 35.f);
         std::vector<cv::Mat> pyrA = ext.mvImagePyramid;
         for (cv::Mat& m : pyrA) m = m.clone();
@@ -74,7 +83,7 @@ int main(int argc, char** argv) {
 
         FILE* fo = fopen(argv[2], "wb");
         if (!fo) return 6;
-        const int counts[8] = {F1.N, F2.N, nInit, nProj, (int)area.size(), dd, (int)pyrA.size(), 0};
+        const int counts[8] = {F1.N, F2.N, nInit, nProj, (int)area.size(), dd, (int)pyrA.size(), 1};
         put(fo, counts, 8);
         put(fo, F1.mvKeys.data(), F1.mvKeys.size());
         for (int i = 0; i < F1.N; i++) put(fo, F1.mDescriptors.ptr<unsigned char>(i), 32);
@@ -90,6 +99,11 @@ int main(int argc, char** argv) {
             put(fo, wh, 2);
             for (int r = 0; r < m.rows; r++) put(fo, m.ptr<unsigned char>(r), (size_t)m.cols);
         }
+        // counts[7] == 1: undistorted keypoints of both frames and the image bounds follow
+        put(fo, F1.mvKeysUn.data(), F1.mvKeysUn.size());
+        put(fo, F2.mvKeysUn.data(), F2.mvKeysUn.size());
+        const float bounds[4] = {Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY};
+        put(fo, bounds, 4);
         fclose(fo);
         for (MapPoint* p : owned) delete p;
     } catch (const std::exception& e) {

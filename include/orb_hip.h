@@ -125,6 +125,29 @@ int orb_resize(orb_ctx* ctx, const uint8_t* src, int sw, int sh, int sstride, ui
                int area);
 int orb_gaussian_blur(orb_ctx* ctx, const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
 
+/* ---- Frame constructor tail ---------------------------------------------- */
+
+/* Frame::UndistortKeyPoints (declared at include/Frame.h:121; body as in
+ * upstream ORB-SLAM2): cv::undistortPoints(pts, pts, mK, mDistCoef, noArray(),
+ * mK) on the keypoint positions, every other field copied.  K = fx, fy, cx, cy
+ * of mK; dist = k1, k2, p1, p2, k3 of mDistCoef
+ * (Examples/Monocular/TUM1.yaml:8-17).  k1 == 0 copies the keypoints, as there. */
+int orb_undistort_keypoints(orb_ctx* ctx, const float K[4], const float dist[5], const orb_keypoint* in,
+                            orb_keypoint* out, int n);
+/* The same on n device-resident keypoints (e.g. a whole batch, n = frames * cap). */
+int orb_undistort_keypoints_device(orb_ctx* ctx, const float K[4], const float dist[5], const orb_keypoint* d_in,
+                                   orb_keypoint* d_out, long long n, void* stream);
+
+/* Frame::ComputeImageBounds (include/Frame.h:123): bounds = mnMinX, mnMaxX,
+ * mnMinY, mnMaxY of the undistorted image corners (the image rectangle when
+ * k1 == 0).  The reference keeps them in static members of Frame, set from the
+ * first frame; here the context keeps them, and the windowed matchers
+ * (orb_match_window*, orb_match_projected) build their 64x48 grid over them
+ * from then on.  orb_set_image_bounds installs given bounds, NULL returns to
+ * "the image rectangle of each call". */
+int orb_compute_image_bounds(orb_ctx* ctx, int cols, int rows, const float K[4], const float dist[5], float bounds[4]);
+int orb_set_image_bounds(orb_ctx* ctx, const float bounds[4]);
+
 /* ---- ORBmatcher ---------------------------------------------------------- */
 
 /* ORBmatcher::DescriptorDistance, src/ORBmatcher.cc:460-476 (host, pure). */

@@ -241,3 +241,40 @@ def distinctive_descriptor(desc, self_distance=False):
     med = C.c_int(0)
     i = lib().oro_distinctive(_p(desc), len(desc), int(self_distance), C.byref(med))
     return (i, med.value) if i >= 0 else (-1, None)
+
+
+def set_image_bounds(bounds):
+    """Frame::mnMinX, mnMaxX, mnMinY, mnMaxY for the grid functions above (None = the image rectangle)."""
+    if bounds is None:
+        lib().oro_set_image_bounds(None)
+    else:
+        b = np.ascontiguousarray(bounds, dtype=np.float32)
+        lib().oro_set_image_bounds(_p(b))
+
+
+def undistort_keypoints(kps, K, dist):
+    """Frame::UndistortKeyPoints; K = (fx, fy, cx, cy), dist = (k1, k2, p1, p2, k3)."""
+    kps = np.ascontiguousarray(kps, dtype=KP_DTYPE)
+    out = np.zeros(len(kps), dtype=KP_DTYPE)
+    K = np.ascontiguousarray(K, dtype=np.float32)
+    dist = np.ascontiguousarray(dist, dtype=np.float32)
+    lib().oro_undistort_keypoints(_p(kps), _p(out), len(kps), _p(K), _p(dist))
+    return out
+
+
+def undistort_points(xy, K, dist):
+    xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+    out = np.zeros_like(xy)
+    K = np.ascontiguousarray(K, dtype=np.float32)
+    dist = np.ascontiguousarray(dist, dtype=np.float32)
+    lib().oro_undistort_points(_p(xy), _p(out), len(xy), _p(K), _p(dist))
+    return out
+
+
+def compute_image_bounds(cols, rows, K, dist):
+    """Frame::ComputeImageBounds -> (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+    K = np.ascontiguousarray(K, dtype=np.float32)
+    dist = np.ascontiguousarray(dist, dtype=np.float32)
+    b = np.zeros(4, dtype=np.float32)
+    lib().oro_compute_image_bounds(cols, rows, _p(K), _p(dist), _p(b))
+    return b

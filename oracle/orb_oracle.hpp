@@ -99,9 +99,21 @@ struct FrameGrid {  // the part of Frame the matcher reads
     const KeyPoint* keys = nullptr;
     const uint8_t* desc = nullptr;
     std::vector<std::vector<int>> cells;  // [ix*48+iy]
-    void build(const KeyPoint* k, const uint8_t* d, int n, int imgW, int imgH);
+    // bounds: mnMinX, mnMaxX, mnMinY, mnMaxY (static members of Frame, set from the first frame);
+    // nullptr = the image rectangle (no lens distortion)
+    void build(const KeyPoint* k, const uint8_t* d, int n, int imgW, int imgH, const float* bounds = nullptr);
     std::vector<int> featuresInArea(float x, float y, float r, int minLevel, int maxLevel, unsigned quirks) const;
 };
+
+// cv::undistortPoints(src, dst, K, distCoef, noArray(), K) as Frame::UndistortKeyPoints and
+// Frame::ComputeImageBounds call it (declared at include/Frame.h:121-123, bodies as in upstream
+// ORB-SLAM2): five fixed iterations of the inverse radial-tangential model in double, result
+// re-projected with K and stored as float.  K = fx, fy, cx, cy; dist = k1, k2, p1, p2, k3.
+void undistortPoints(const float* xyIn, float* xyOut, int n, const float K[4], const float dist[5]);
+// Frame::UndistortKeyPoints: positions replaced, everything else copied; k1 == 0 copies the keypoints.
+void undistortKeyPoints(const KeyPoint* in, KeyPoint* out, int n, const float K[4], const float dist[5]);
+// Frame::ComputeImageBounds: bounds = mnMinX, mnMaxX, mnMinY, mnMaxY.
+void computeImageBounds(int cols, int rows, const float K[4], const float dist[5], float bounds[4]);
 
 void computeThreeMaxima(const int* counts, int L, int& i1, int& i2, int& i3);
 

@@ -142,10 +142,29 @@ int oro_hamming_bithack(const uint8_t* a, const uint8_t* b) { return hammingBitH
 int oro_hamming_popcount(const uint8_t* a, const uint8_t* b) { return hammingPopcount(a, b); }
 void oro_three_maxima(const int* counts, int L, int* ind) { computeThreeMaxima(counts, L, ind[0], ind[1], ind[2]); }
 
+// Frame::mnMinX .. mnMaxY are static members set from the first frame; nullptr = image rectangle.
+static float g_bounds[4];
+static bool g_haveBounds = false;
+void oro_set_image_bounds(const float* b) {
+    g_haveBounds = b != nullptr;
+    if (b) memcpy(g_bounds, b, sizeof(g_bounds));
+}
+static const float* bounds() { return g_haveBounds ? g_bounds : nullptr; }
+
+void oro_undistort_keypoints(const KeyPoint* in, KeyPoint* out, int n, const float* K, const float* dist) {
+    undistortKeyPoints(in, out, n, K, dist);
+}
+void oro_undistort_points(const float* in, float* out, int n, const float* K, const float* dist) {
+    undistortPoints(in, out, n, K, dist);
+}
+void oro_compute_image_bounds(int cols, int rows, const float* K, const float* dist, float* b) {
+    computeImageBounds(cols, rows, K, dist, b);
+}
+
 int oro_features_in_area(const KeyPoint* k, int n, int imgW, int imgH, float x, float y, float r, int minLevel,
                          int maxLevel, unsigned quirks, int* out, int cap) {
     FrameGrid g;
-    g.build(k, nullptr, n, imgW, imgH);
+    g.build(k, nullptr, n, imgW, imgH, bounds());
     std::vector<int> v = g.featuresInArea(x, y, r, minLevel, maxLevel, quirks);
     const int m = std::min((int)v.size(), cap);
     if (m > 0) memcpy(out, v.data(), (size_t)m * sizeof(int));
@@ -156,8 +175,8 @@ int oro_search_for_initialization(const KeyPoint* k1, const uint8_t* d1, int n1,
                                   int n2, int imgW, int imgH, float* prevXY, int* matches12, int window, float nnratio,
                                   int checkOri, unsigned quirks) {
     FrameGrid F1, F2;
-    F1.build(k1, d1, n1, imgW, imgH);
-    F2.build(k2, d2, n2, imgW, imgH);
+    F1.build(k1, d1, n1, imgW, imgH, bounds());
+    F2.build(k2, d2, n2, imgW, imgH, bounds());
     return searchForInitialization(F1, F2, prevXY, matches12, window, nnratio, checkOri != 0, quirks);
 }
 
@@ -166,7 +185,7 @@ int oro_search_by_projection(const float* u, const float* v, const float* radius
                              int nq, const KeyPoint* k2, const uint8_t* d2, int n2, int imgW, int imgH,
                              const uint8_t* occupied2, int* match2, int thHigh, int checkOri, unsigned quirks) {
     FrameGrid F2;
-    F2.build(k2, d2, n2, imgW, imgH);
+    F2.build(k2, d2, n2, imgW, imgH, bounds());
     return searchByProjection(u, v, radius, minLevel, maxLevel, qangle, qdesc, qobs, nq, F2, occupied2, match2, thHigh,
                               checkOri != 0, quirks);
 }

@@ -48,14 +48,14 @@ int hammingPopcount(const uint8_t* a, const uint8_t* b) {
 // grid element inverses are 64/(maxX-minX), 48/(maxY-minY); a keypoint goes to
 // cell (round((x-minX)*wInv), round((y-minY)*hInv)) unless that falls outside
 // the grid; cell lists hold indices in increasing order.
-void FrameGrid::build(const KeyPoint* k, const uint8_t* d, int n, int imgW, int imgH) {
+void FrameGrid::build(const KeyPoint* k, const uint8_t* d, int n, int imgW, int imgH, const float* bounds) {
     keys = k;
     desc = d;
     N = n;
-    minX = 0.f;
-    maxX = (float)imgW;
-    minY = 0.f;
-    maxY = (float)imgH;
+    minX = bounds ? bounds[0] : 0.f;
+    maxX = bounds ? bounds[1] : (float)imgW;
+    minY = bounds ? bounds[2] : 0.f;
+    maxY = bounds ? bounds[3] : (float)imgH;
     wInv = static_cast<float>(GRID_COLS) / (maxX - minX);
     hInv = static_cast<float>(GRID_ROWS) / (maxY - minY);
     cells.assign(GRID_COLS * GRID_ROWS, {});
@@ -64,6 +64,80 @@ void FrameGrid::build(const KeyPoint* k, const uint8_t* d, int n, int imgW, int 
         const int posY = (int)round((k[i].y - minY) * hInv);
         if (posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS) continue;
         cells[posX * GRID_ROWS + posY].push_back(i);
+    }
+}
+
+// cvUndistortPointsInternal of OpenCV 4.2 for the call undistortPoints(src, dst, K, D, noArray(), K):
+// criteria (MAX_ITER, 5), no tilt, R = I, P = K; all arithmetic in double, operation order as there.
+void undistortPoints(const float* xyIn, float* xyOut, int n, const float K[4], const float dist[5]) {
+    double k[14] = {0};
+    k[0] = dist[0];
+    k[1] = dist[1];
+    k[2] = dist[2];
+    k[3] = dist[3];
+    k[4] = dist[4];
+    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+    const double ifx = 1. / fx, ify = 1. / fy;
+    for (int i = 0; i < n; i++) {
+        double x = xyIn[2 * i], y = xyIn[2 * i + 1];
+        const double u = x, v = y;
+        x = (x - cx) * ifx;
+        y = (y - cy) * ify;
+        const double x0 = x, y0 = y;
+        for (int j = 0; j < 5; j++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            if (icdist < 0) {  // the model is not invertible there: the undistorted point is the normalised input
+                x = (u - cx) * ifx;
+                y = (v - cy) * ify;
+                break;
+            }
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        // RR = P * R = K: xx = fx*x + 0*y + cx, yy = 0*x + fy*y + cy, ww = 1 / (0*x + 0*y + 1)
+        const double xx = fx * x + 0. * y + cx;
+        const double yy = 0. * x + fy * y + cy;
+        const double ww = 1. / (0. * x + 0. * y + 1.);
+        xyOut[2 * i] = (float)(xx * ww);
+        xyOut[2 * i + 1] = (float)(yy * ww);
+    }
+}
+
+void undistortKeyPoints(const KeyPoint* in, KeyPoint* out, int n, const float K[4], const float dist[5]) {
+    if (dist[0] == 0.0f) {  // if(mDistCoef.at<float>(0)==0.0) mvKeysUn = mvKeys
+        for (int i = 0; i < n; i++) out[i] = in[i];
+        return;
+    }
+    std::vector<float> mat((size_t)2 * n);
+    for (int i = 0; i < n; i++) {
+        mat[2 * i] = in[i].x;
+        mat[2 * i + 1] = in[i].y;
+    }
+    undistortPoints(mat.data(), mat.data(), n, K, dist);
+    for (int i = 0; i < n; i++) {
+        KeyPoint kp = in[i];
+        kp.x = mat[2 * i];
+        kp.y = mat[2 * i + 1];
+        out[i] = kp;
+    }
+}
+
+void computeImageBounds(int cols, int rows, const float K[4], const float dist[5], float bounds[4]) {
+    if (dist[0] != 0.0f) {
+        float mat[8] = {0.f, 0.f, (float)cols, 0.f, 0.f, (float)rows, (float)cols, (float)rows};
+        undistortPoints(mat, mat, 4, K, dist);
+        bounds[0] = std::min(mat[0], mat[4]);  // mnMinX = min(mat(0,0), mat(2,0))
+        bounds[1] = std::max(mat[2], mat[6]);  // mnMaxX = max(mat(1,0), mat(3,0))
+        bounds[2] = std::min(mat[1], mat[3]);  // mnMinY = min(mat(0,1), mat(1,1))
+        bounds[3] = std::max(mat[5], mat[7]);  // mnMaxY = max(mat(2,1), mat(3,1))
+    } else {
+        bounds[0] = 0.0f;
+        bounds[1] = (float)cols;
+        bounds[2] = 0.0f;
+        bounds[3] = (float)rows;
     }
 }
 

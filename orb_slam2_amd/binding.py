@@ -31,6 +31,7 @@ EXPORTS = [
     "orb_bf_set_database_device", "orb_bf_query_top2", "orb_bf_query_packed_device", "orb_bf_merge_packed_device",
     "orb_enable_stage_timing", "orb_get_stage_timings", "orb_last_error", "orb_version",
     "orb_distinctive_descriptors", "orb_distinctive_descriptors_device",
+    "orb_undistort_keypoints", "orb_undistort_keypoints_device", "orb_compute_image_bounds", "orb_set_image_bounds",
 ]
 
 
@@ -237,6 +238,32 @@ class Context:
                                          _p(qdesc), _p(qobs), len(u), _p(k2), _p(d2), len(k2), img_w, img_h, _p(occ),
                                          _p(match2), th_high, int(check_ori), C.byref(nm)))
         return nm.value, match2[: len(k2)]
+
+    def undistort_keypoints(self, kps, K, dist):
+        """Frame::UndistortKeyPoints; K = (fx, fy, cx, cy), dist = (k1, k2, p1, p2, k3)."""
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        out = np.zeros(len(kps), KP_DTYPE)
+        K = np.ascontiguousarray(K, np.float32)
+        dist = np.ascontiguousarray(dist, np.float32)
+        _check(lib().orb_undistort_keypoints(self.h, _p(K), _p(dist), _p(kps), _p(out), len(kps)))
+        return out
+
+    def undistort_keypoints_device(self, d_in, d_out, n, K, dist, stream=None):
+        K = np.ascontiguousarray(K, np.float32)
+        dist = np.ascontiguousarray(dist, np.float32)
+        _check(lib().orb_undistort_keypoints_device(self.h, _p(K), _p(dist), _dp(d_in), _dp(d_out), C.c_longlong(n), _stream(stream)))
+
+    def compute_image_bounds(self, cols, rows, K, dist):
+        """Frame::ComputeImageBounds; the context keeps the bounds for the windowed matchers."""
+        K = np.ascontiguousarray(K, np.float32)
+        dist = np.ascontiguousarray(dist, np.float32)
+        b = np.zeros(4, np.float32)
+        _check(lib().orb_compute_image_bounds(self.h, cols, rows, _p(K), _p(dist), _p(b)))
+        return b
+
+    def set_image_bounds(self, bounds):
+        b = None if bounds is None else np.ascontiguousarray(bounds, np.float32)
+        _check(lib().orb_set_image_bounds(self.h, _p(b)))
 
     def distinctive_descriptors(self, desc, offsets, self_distance=False):
         """MapPoint::ComputeDistinctiveDescriptors for the map points whose observation descriptors are

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <stdexcept>
+#include <string>
 
 #include "../../include/orb_hip.h"
 
@@ -79,6 +80,11 @@ Frame::Frame(const cv::Mat& imGray, const double& timeStamp, ORBextractor* extra
         mbInitialComputations = false;
     }
     mb = fx != 0.f ? mbf / fx : 0.f;
+    {   // the matcher kernels lay their grid over the same (static) bounds, whichever extractor made this frame
+        const float b[4] = {mnMinX, mnMaxX, mnMinY, mnMaxY};
+        if (orb_set_image_bounds(mpORBextractorLeft->Context(), b) != ORB_OK)
+            throw std::runtime_error(std::string("Frame: ") + orb_last_error());
+    }
     AssignFeaturesToGrid();
 }
 
@@ -91,21 +97,45 @@ void Frame::ExtractORB(int flag, const cv::Mat& im) {
 
 void Frame::SetPose(cv::Mat Tcw) { mTcw = Tcw.clone(); }
 
-// Lens distortion is outside the front end's scope: keypoints are taken as undistorted.
-void Frame::UndistortKeyPoints() {
-    if (!mDistCoef.empty()) {
-        for (int i = 0; i < mDistCoef.rows * mDistCoef.cols; i++)
-            if (mDistCoef.at<float>(i) != 0.f)
-                throw std::runtime_error("Frame: non-zero distortion coefficients are not supported by this front end");
-    }
-    mvKeysUn = mvKeys;
+// Camera matrix and distortion coefficients in the plain form the C ABI takes.  mDistCoef holds
+// k1, k2, p1, p2 and, when non-zero, k3 (src/Tracking.cc:76-88).
+static bool CameraArrays(const cv::Mat& K, const cv::Mat& D, float k[4], float d[5]) {
+    for (int i = 0; i < 5; i++) d[i] = 0.f;
+    if (K.empty()) return false;
+    k[0] = K.at<float>(0, 0);
+    k[1] = K.at<float>(1, 1);
+    k[2] = K.at<float>(0, 2);
+    k[3] = K.at<float>(1, 2);
+    const int nd = D.empty() ? 0 : std::min(5, D.rows * D.cols);
+    for (int i = 0; i < nd; i++) d[i] = D.at<float>(i);
+    return true;
 }
 
+// Upstream ORB-SLAM2 Frame::UndistortKeyPoints (the fork only declares it, include/Frame.h:121).
+void Frame::UndistortKeyPoints() {
+    float k[4], d[5];
+    if (!CameraArrays(mK, mDistCoef, k, d) || d[0] == 0.0f) {
+        mvKeysUn = mvKeys;
+        return;
+    }
+    static_assert(sizeof(cv::KeyPoint) == sizeof(orb_keypoint), "cv::KeyPoint must be the 28-byte OpenCV layout");
+    mvKeysUn.resize(N);
+    if (orb_undistort_keypoints(mpORBextractorLeft->Context(), k, d, reinterpret_cast<const orb_keypoint*>(mvKeys.data()),
+                                reinterpret_cast<orb_keypoint*>(mvKeysUn.data()), N) != ORB_OK)
+        throw std::runtime_error(std::string("Frame::UndistortKeyPoints: ") + orb_last_error());
+}
+
+// Upstream ORB-SLAM2 Frame::ComputeImageBounds (include/Frame.h:123).
 void Frame::ComputeImageBounds(const cv::Mat& imLeft) {
-    mnMinX = 0.0f;
-    mnMaxX = (float)imLeft.cols;
-    mnMinY = 0.0f;
-    mnMaxY = (float)imLeft.rows;
+    float k[4], d[5], b[4] = {0.0f, (float)imLeft.cols, 0.0f, (float)imLeft.rows};
+    if (CameraArrays(mK, mDistCoef, k, d) && d[0] != 0.0f) {
+        if (orb_compute_image_bounds(mpORBextractorLeft->Context(), imLeft.cols, imLeft.rows, k, d, b) != ORB_OK)
+            throw std::runtime_error(std::string("Frame::ComputeImageBounds: ") + orb_last_error());
+    }
+    mnMinX = b[0];
+    mnMaxX = b[1];
+    mnMinY = b[2];
+    mnMaxY = b[3];
 }
 
 bool Frame::PosInGrid(const cv::KeyPoint& kp, int& posX, int& posY) {

@@ -97,21 +97,26 @@ static __device__ __forceinline__ void wave_lds_order() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Frame::mnMinX .. mnMaxY and the grid element inverses (upstream Frame.cc constructor tail).
+struct GridGeom {
+    float minX, maxX, minY, maxY, wInv, hInv;
+};
+
 struct Window {
     int x0, x1, y0, y1;  // bucket ranges [x0,x1) x [y0,y1); empty when x1 <= x0
 };
 
 // Bucket range of GetFeaturesInArea(x, y, r), src/Frame.cc:91-112.
-static __device__ __forceinline__ Window window_cells(float x, float y, float r, float wInv, float hInv, bool excl) {
+static __device__ __forceinline__ Window window_cells(float x, float y, float r, const GridGeom& G, bool excl) {
     Window w;
     w.x0 = w.x1 = w.y0 = w.y1 = 0;
-    const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(x, r), wInv)));
+    const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, G.minX), r), G.wInv)));
     if (nMinCellX >= ORB_GRID_COLS) return w;
-    const int nMaxCellX = min(ORB_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(x, r), wInv)));
+    const int nMaxCellX = min(ORB_GRID_COLS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, G.minX), r), G.wInv)));
     if (nMaxCellX < 0) return w;
-    const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(y, r), hInv)));
+    const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, G.minY), r), G.hInv)));
     if (excl ? nMinCellY > ORB_GRID_ROWS : nMinCellY >= ORB_GRID_ROWS) return w;
-    const int nMaxCellY = min(ORB_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(y, r), hInv)));
+    const int nMaxCellY = min(ORB_GRID_ROWS - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, G.minY), r), G.hInv)));
     if (nMaxCellY < 0) return w;
     w.x0 = nMinCellX;
     w.x1 = excl ? nMaxCellX : nMaxCellX + 1;
@@ -178,7 +183,7 @@ struct MatchBuffers {
 // Kernel 1.  Bucket assignment as the Frame constructor does it (PosInGrid): rounded position,
 // keypoints that fall outside the grid are left out.
 __global__ __launch_bounds__(256) void k_grid_build(const orb_keypoint* __restrict__ k2all, const int* __restrict__ n2s,
-                                                    int n2const, int stride2, float imgW, float imgH, MatchBuffers B,
+                                                    int n2const, int stride2, GridGeom G, MatchBuffers B,
                                                     int* __restrict__ error) {
     __shared__ uint32_t s_sorted[M_MAXKP];
     __shared__ uint32_t s_key[M_MAXKP];
@@ -196,14 +201,13 @@ __global__ __launch_bounds__(256) void k_grid_build(const orb_keypoint* __restri
         for (int c = t; c <= M_CELLS; c += 256) cellStart[c] = 0;  // an empty grid: the later kernels find nothing
         return;
     }
-    const float wInv = __fdiv_rn((float)ORB_GRID_COLS, imgW), hInv = __fdiv_rn((float)ORB_GRID_ROWS, imgH);
     // Counting sort by bucket: histogram, prefix sum, scatter; a bucket's few entries are then put in
     // index order by one thread (the scatter's order depends on how the atomics were served).
     for (int c = t; c <= M_CELLS; c += 256) s_start[c] = 0;
     __syncthreads();
     for (int i = t; i < n2; i += 256) {
-        const int px = (int)roundf(__fmul_rn(k2[i].x, wInv));  // mnMinX = mnMinY = 0: no lens distortion
-        const int py = (int)roundf(__fmul_rn(k2[i].y, hInv));
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(k2[i].x, G.minX), G.wInv));  // Frame::PosInGrid
+        const int py = (int)roundf(__fmul_rn(__fsub_rn(k2[i].y, G.minY), G.hInv));
         uint32_t key = 0xFFFFFFFFu;
         if (px >= 0 && px < ORB_GRID_COLS && py >= 0 && py < ORB_GRID_ROWS) {
             key = ((uint32_t)(px * ORB_GRID_ROWS + py) << 16) | (uint32_t)i;
@@ -301,8 +305,8 @@ __global__ __launch_bounds__(256) void k_match_lists(const orb_keypoint* __restr
                                                      float window, const float* __restrict__ u,
                                                      const float* __restrict__ v, const float* __restrict__ radius,
                                                      const int* __restrict__ minLevel, const int* __restrict__ maxLevel,
-                                                     const uint8_t* __restrict__ d2all, int stride2, float imgW,
-                                                     float imgH, unsigned quirks, MatchBuffers B) {
+                                                     const uint8_t* __restrict__ d2all, int stride2, GridGeom G,
+                                                     unsigned quirks, MatchBuffers B) {
     const int pair = blockIdx.y, lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nq = PROJECTED ? nqConst : n1s[pair];
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256) void k_match_lists(const orb_keypoint* __restr
         r = radius[q];
         lmin = minLevel[q];
         lmax = maxLevel[q];
-        active = !(x < 0.f || x > imgW) && !(y < 0.f || y > imgH);  // :323-326
+        active = !(x < G.minX || x > G.maxX) && !(y < G.minY || y > G.maxY);  // :323-326
     } else {
         const orb_keypoint kp1 = k1all[(int64_t)pair * stride1 + q];
         x = prevAll[((int64_t)pair * stride1 + q) * 2];
@@ -327,10 +331,9 @@ __global__ __launch_bounds__(256) void k_match_lists(const orb_keypoint* __restr
         active = !(kp1.octave > 0);  // :41-44
     }
     const bool excl = (quirks & ORB_Q_GRID_EXCLUSIVE) != 0, circ = (quirks & ORB_Q_WINDOW_CIRCULAR) != 0;
-    const float wInv = __fdiv_rn((float)ORB_GRID_COLS, imgW), hInv = __fdiv_rn((float)ORB_GRID_ROWS, imgH);
     Window w;
     w.x0 = w.x1 = w.y0 = w.y1 = 0;
-    if (active) w = window_cells(x, y, r, wInv, hInv, excl);
+    if (active) w = window_cells(x, y, r, G, excl);
     if (!active || w.x1 <= w.x0 || w.y1 <= w.y0) {
         if (lane == 0) counts[q] = 0;
         return;
@@ -717,6 +720,28 @@ static int match_buffers(orb_ctx* c, int npairs, int stride1, int stride2, Match
     return ORB_OK;
 }
 
+int orb_ctx_get_bounds(const orb_ctx* c, float b[4]);
+
+// Grid geometry of the frames being matched: the context's image bounds when set (lens distortion),
+// else the image rectangle; inverses as the Frame constructor computes them.
+static GridGeom grid_geom(const orb_ctx* c, int img_w, int img_h) {
+    float b[4];
+    if (!orb_ctx_get_bounds(c, b)) {
+        b[0] = 0.f;
+        b[1] = (float)img_w;
+        b[2] = 0.f;
+        b[3] = (float)img_h;
+    }
+    GridGeom G;
+    G.minX = b[0];
+    G.maxX = b[1];
+    G.minY = b[2];
+    G.maxY = b[3];
+    G.wInv = static_cast<float>(ORB_GRID_COLS) / static_cast<float>(b[1] - b[0]);
+    G.hInv = static_cast<float>(ORB_GRID_ROWS) / static_cast<float>(b[3] - b[2]);
+    return G;
+}
+
 static int check_match_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -751,13 +776,13 @@ extern "C" int orb_match_window_batch_device(orb_ctx* c, int npairs, const orb_k
     int rc = match_buffers(c, npairs, stride1, stride2, &s, &B);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(256), 0, st, d_k2, d_n2, 0, stride2, (float)img_w, (float)img_h, B,
+    const GridGeom G = grid_geom(c, img_w, img_h);
+    hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(256), 0, st, d_k2, d_n2, 0, stride2, G, B,
                        (int*)s->err);
     if ((rc = check_match_launch())) return rc;
     hipLaunchKernelGGL(k_match_lists<false>, dim3((stride1 + 3) / 4, npairs), dim3(256), 0, st, d_k1, d_d1, d_n1, 0,
                        stride1, (const float*)d_prev_xy, (float)window, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const int*)nullptr, (const int*)nullptr, d_d2, stride2, (float)img_w,
-                       (float)img_h, orb_ctx_quirks(c), B);
+                       (const float*)nullptr, (const int*)nullptr, (const int*)nullptr, d_d2, stride2, G, orb_ctx_quirks(c), B);
     if ((rc = check_match_launch())) return rc;
     hipLaunchKernelGGL(k_match_resolve<false>, dim3(npairs), dim3(256), 0, st, d_k1, d_n1, 0, stride1, d_k2, d_n2, 0,
                        stride2, d_prev_xy, d_matches12, (uint8_t*)s->binOf, (const float*)nullptr,
@@ -866,13 +891,14 @@ extern "C" int orb_match_projected(orb_ctx* c, const float* u, const float* v, c
     HIP_TRY(tm.put(nullptr, (size_t)n2 * 4));
     HIP_TRY(tnm.put(nullptr, 4));
     hipStream_t st = nullptr;
+    const GridGeom G = grid_geom(c, img_w, img_h);
     hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, st, (const orb_keypoint*)tk2.p, (const int*)nullptr, n2, n2,
-                       (float)img_w, (float)img_h, B, (int*)s->err);
+                       G, B, (int*)s->err);
     if ((rc = check_match_launch())) return rc;
     hipLaunchKernelGGL(k_match_lists<true>, dim3((nq + 3) / 4, 1), dim3(256), 0, st, (const orb_keypoint*)nullptr,
                        (const uint8_t*)tq.p, (const int*)nullptr, nq, nq, (const float*)nullptr, 0.f, (const float*)tu.p,
                        (const float*)tv.p, (const float*)tr.p, (const int*)tl0.p, (const int*)tl1.p,
-                       (const uint8_t*)td2.p, n2, (float)img_w, (float)img_h, orb_ctx_quirks(c), B);
+                       (const uint8_t*)td2.p, n2, G, orb_ctx_quirks(c), B);
     if ((rc = check_match_launch())) return rc;
     hipLaunchKernelGGL(k_match_resolve<true>, dim3(1), dim3(256), 0, st, (const orb_keypoint*)nullptr,
                        (const int*)nullptr, nq, nq, (const orb_keypoint*)tk2.p, (const int*)nullptr, n2, n2,

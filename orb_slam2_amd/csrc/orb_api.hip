@@ -94,6 +94,10 @@ struct orb_ctx {
     const uint8_t* lastImg0 = nullptr;
     int lastStride0 = 0;
     int64_t lastFrameStride0 = 0;
+    // Frame::mnMinX, mnMaxX, mnMinY, mnMaxY (static members of Frame in the reference, set from the
+    // first frame): used by the windowed matchers when set, else the image rectangle
+    bool haveBounds = false;
+    float bounds[4] = {0, 0, 0, 0};
     // matcher scratch lives in kernels_match.hip
     void* matchState = nullptr;
     // stage timing: ring of event sets, one set (5 events) per recorded batch
@@ -110,6 +114,14 @@ int orb_ctx_device(const orb_ctx* c) { return c->prm.device; }
 unsigned orb_ctx_quirks(const orb_ctx* c) { return c->prm.quirks; }
 int orb_ctx_max_batch(const orb_ctx* c) { return c->prm.max_batch; }
 void** orb_ctx_match_state(orb_ctx* c) { return &c->matchState; }
+int orb_ctx_get_bounds(const orb_ctx* c, float b[4]) {
+    if (c->haveBounds) memcpy(b, c->bounds, sizeof(c->bounds));
+    return c->haveBounds ? 1 : 0;
+}
+void orb_ctx_store_bounds(orb_ctx* c, const float* b) {
+    c->haveBounds = b != nullptr;
+    if (b) memcpy(c->bounds, b, sizeof(c->bounds));
+}
 
 // ORBextractor::ORBextractor, src/ORBextractor.cc:369-436 (inverse tables divide by the forward tables).
 static int build_tables(orb_ctx* c) {

@@ -121,6 +121,76 @@ def test_cpp_dropin_demo(oracle, tmp_path, preset):
     assert npo > 100
 
 
+def test_cpp_dropin_demo_with_lens_distortion(oracle, tmp_path):
+    """The drop-in Frame with Examples/Monocular/TUM1.yaml's camera: UndistortKeyPoints, ComputeImageBounds, the grid
+    over the undistorted bounds and both searches on mvKeysUn."""
+    exe = os.path.join(ROOT, "examples", "orb_demo")
+    quirks = oracle.QUIRKS_FORK
+    w, h, nf, window, ratio = 640, 480, 1000, 100, 0.9
+    K = (517.306408, 516.469215, 318.643040, 255.313989)
+    D = (0.262383, -0.953104, -0.005358, 0.002628, 1.163314)
+    a = synth_scene(w, h, frame_seed(1, 9))
+    b = synth_scene(w, h, frame_seed(1, 9), shift=(2, 3), noise_seed=1234)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<iiiif", w, h, nf, window, ratio))
+        f.write(a.tobytes())
+        f.write(b.tobytes())
+    env = dict(os.environ, ORBHIP_QUIRKS=str(quirks), ORBDEMO_CAMERA=",".join("%.9g" % v for v in K + D))
+    subprocess.check_call([exe, fin, fout], env=env, timeout=120)
+    raw = open(fout, "rb").read()
+    cnt = np.frombuffer(raw, np.int32, 8)
+    n1, n2, n_init, n_proj, n_area, dd, nlev, has_un = (int(v) for v in cnt)
+    assert has_un == 1
+    off = 32
+    KP = oracle.KP_DTYPE
+
+    def take(dtype, n):
+        nonlocal off
+        arr = np.frombuffer(raw, dtype, n, off)
+        off += arr.nbytes
+        return arr
+
+    k1 = take(KP, n1); d1 = take(np.uint8, n1 * 32).reshape(n1, 32)
+    k2 = take(KP, n2); d2 = take(np.uint8, n2 * 32).reshape(n2, 32)
+    m12 = take(np.int32, n1); prev = take(np.float32, 2 * n1).reshape(n1, 2)
+    proj = take(np.int32, n2); area = take(np.int32, n_area)
+    for l in range(nlev):
+        wl, hl = (int(v) for v in take(np.int32, 2))
+        take(np.uint8, wl * hl)
+    k1u = take(KP, n1); k2u = take(KP, n2); bounds = take(np.float32, 4)
+    e = oracle.Extractor(nf, 1.2, 8, 20, 7, quirks)
+    ko1, do1 = e.extract(a)
+    ko2, do2 = e.extract(b)
+    assert (k1 == ko1).all() and (d1 == do1).all() and (k2 == ko2).all() and (d2 == do2).all()
+    Kf, Df = np.float32(K), np.float32(D)
+    uo1, uo2 = oracle.undistort_keypoints(ko1, Kf, Df), oracle.undistort_keypoints(ko2, Kf, Df)
+    assert (k1u == uo1).all() and (k2u == uo2).all()
+    np.testing.assert_array_equal(bounds, oracle.compute_image_bounds(w, h, Kf, Df))
+    oracle.set_image_bounds(bounds)
+    try:
+        prev0 = np.stack([uo1["x"], uo1["y"]], axis=1).astype(np.float32)
+        no, mo, po = oracle.search_for_initialization(uo1, do1, uo2, do2, w, h, prev0, window, ratio, True, quirks)
+        assert n_init == no and (m12 == mo).all() and (prev == po).all() and no > 50
+        assert (area == oracle.features_in_area(uo2, w, h, w / 2.0, h / 2.0, 60.0, 0, 2, quirks)).all()
+        # SearchByProjection: the demo's float arithmetic with this camera (identity pose, depth 2)
+        fx, fy, cx, cy = (_f32(v) for v in K)
+        invfx, invfy, z = _f32(1.0) / fx, _f32(1.0) / fy, _f32(2.0)
+        X = (uo1["x"] - cx) * invfx * z
+        Y = (uo1["y"] - cy) * invfy * z
+        invz = _f32(1.0 / 2.0)
+        u = fx * X * invz + cx
+        v = fy * Y * invz + cy
+        radius = _f32(15.0) * e.tables()["scale"][uo1["octave"]]
+        qobs = (np.arange(n1) % 5 != 0).astype(np.uint8)
+        npo, match2 = oracle.search_by_projection(u, v, radius, uo1["octave"] - 1, uo1["octave"] + 1, uo1["angle"], do1, qobs,
+                                                  uo2, do2, w, h, None, 100, True, quirks)
+        assert n_proj == npo and npo > 100
+        assert (proj == np.where(match2 >= 0, match2, -1)).all()
+    finally:
+        oracle.set_image_bounds(None)
+
+
 def test_properties_at_full_sizes(hip):
     """Config-scale checks that need no oracle run: (a) every descriptor's distance to itself is 0 and the
     brute-force scan of a set against itself returns the identity with second >= best; (b) extraction is

@@ -336,6 +336,71 @@ def test_brute_force_sharded_merge(hip, oracle):
             bf.close()
 
 
+TUM1_K = (517.306408, 516.469215, 318.643040, 255.313989)
+TUM1_D = (0.262383, -0.953104, -0.005358, 0.002628, 1.163314)
+
+
+def test_undistort_and_image_bounds(hip, oracle):
+    c = _ctx(hip, "fork")
+    e = oracle.Extractor(1000, 1.2, 8, 20, 7, PRESETS["fork"])
+    k, _ = e.extract(synth_scene(640, 480, frame_seed(1, 3)))
+    extra = np.zeros(6, oracle.KP_DTYPE)  # corners, principal point, a point outside the image
+    extra["x"] = [0, 640, 0, 640, TUM1_K[2], -50]
+    extra["y"] = [0, 0, 480, 480, TUM1_K[3], 700]
+    k = np.concatenate([k, extra])
+    for D in (TUM1_D, (0, 0, 0, 0, 0), (-0.28, 0.07, 0.0002, 0.00002, 0.0), (1e-9, 0, 0, 0, 0)):
+        got, ref = c.undistort_keypoints(k, TUM1_K, D), oracle.undistort_keypoints(k, TUM1_K, D)
+        assert (got == ref).all(), "undistorted keypoints differ for D=%s" % (D,)
+        np.testing.assert_array_equal(c.compute_image_bounds(640, 480, TUM1_K, D), oracle.compute_image_bounds(640, 480, TUM1_K, D))
+    import torch
+
+    d_in = torch.from_numpy(k.view(np.uint8).reshape(-1, 28).copy()).cuda()
+    d_out = torch.zeros_like(d_in)
+    c.undistort_keypoints_device(d_in, d_out, len(k), TUM1_K, TUM1_D)
+    torch.cuda.synchronize()
+    assert (d_out.cpu().numpy().view(oracle.KP_DTYPE).reshape(-1) == oracle.undistort_keypoints(k, TUM1_K, TUM1_D)).all()
+    c.set_image_bounds(None)
+    c.close()
+
+
+@pytest.mark.parametrize("preset", ["fork", "canonical"])
+def test_matchers_with_undistorted_bounds(hip, oracle, preset):
+    """Both windowed searches on undistorted keypoints with the grid laid over the undistorted image bounds."""
+    q = PRESETS[preset]
+    w, h = 640, 480
+    c = _ctx(hip, preset)
+    e = oracle.Extractor(1000, 1.2, 8, 20, 7, q)
+    a = synth_scene(w, h, frame_seed(1, 21))
+    b = synth_scene(w, h, frame_seed(1, 21), shift=(4, -3), noise_seed=99)
+    k1, d1 = e.extract(a)
+    k2, d2 = e.extract(b)
+    k1u, k2u = oracle.undistort_keypoints(k1, TUM1_K, TUM1_D), oracle.undistort_keypoints(k2, TUM1_K, TUM1_D)
+    bounds = c.compute_image_bounds(w, h, TUM1_K, TUM1_D)
+    oracle.set_image_bounds(bounds)
+    try:
+        prev0 = np.stack([k1u["x"], k1u["y"]], axis=1).astype(np.float32)
+        no, mo, po = oracle.search_for_initialization(k1u, d1, k2u, d2, w, h, prev0, 100, 0.9, True, q)
+        ng, mg, pg = c.match_window(k1u, d1, k2u, d2, w, h, prev0, 100, 0.9, True)
+        assert ng == no and no > 20
+        np.testing.assert_array_equal(mg, mo)
+        np.testing.assert_array_equal(pg, po)
+        # projected search: queries = frame-1 keypoints near the bounds as well as inside
+        n = len(k1u)
+        u = k1u["x"] + np.float32(2.5)
+        v = k1u["y"] - np.float32(1.5)
+        u[:5] = [bounds[0] - 1, bounds[1] + 1, bounds[0], bounds[1], bounds[0] + 0.5]
+        rad = np.full(n, 15.0, np.float32) * (np.float32(1.2) ** k1u["octave"]).astype(np.float32)
+        lvl = k1u["octave"].astype(np.int32)
+        no, m2o = oracle.search_by_projection(u, v, rad, lvl - 1, lvl + 1, k1u["angle"], d1, None, k2u, d2, w, h, None, 100, True, q)
+        ng, m2g = c.match_projected(u, v, rad, lvl - 1, lvl + 1, k1u["angle"], d1, None, k2u, d2, w, h, None, 100, True)
+        assert ng == no and no > 20
+        np.testing.assert_array_equal(m2g, m2o)
+    finally:
+        oracle.set_image_bounds(None)
+        c.set_image_bounds(None)
+    c.close()
+
+
 def test_distinctive_descriptors(hip, oracle):
     """MapPoint::ComputeDistinctiveDescriptors batched: ragged lists incl. empty, 1, 2, 64, 65, > LDS capacity,
     near-duplicate descriptors (many ties), both the fork's self-comparison and upstream behaviour."""

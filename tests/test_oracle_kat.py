@@ -226,3 +226,32 @@ def test_distinctive_descriptor_known_answers(oracle):
     # the fork's self-comparison at :195 makes every distance 0
     assert oracle.distinctive_descriptor(np.stack([d(40), d(8), z]), self_distance=True) == (0, 0)
     assert oracle.distinctive_descriptor(np.zeros((0, 32), np.uint8)) == (-1, None)
+
+
+def test_undistortion_known_answers(oracle):
+    """Frame::UndistortKeyPoints / ComputeImageBounds through cv::undistortPoints(.., K, D, noArray(), K)."""
+    K = (517.306408, 516.469215, 318.643040, 255.313989)      # Examples/Monocular/TUM1.yaml:8-11
+    D = (0.262383, -0.953104, -0.005358, 0.002628, 1.163314)  # :13-17
+    # no distortion: bounds are the image rectangle, keypoints are copied
+    assert list(oracle.compute_image_bounds(640, 480, K, (0, 0, 0, 0, 0))) == [0.0, 640.0, 0.0, 480.0]
+    kps = np.zeros(3, oracle.KP_DTYPE)
+    kps["x"], kps["y"], kps["octave"] = [10.5, 320, 600], [20.25, 240, 470], [0, 3, 7]
+    assert (oracle.undistort_keypoints(kps, K, (0, 0, 0, 0, 0)) == kps).all()
+    # the principal point is a fixed point of the model; every other field is copied
+    pp = oracle.undistort_points([[K[2], K[3]]], K, D)
+    assert abs(pp[0, 0] - np.float32(K[2])) < 1e-4 and abs(pp[0, 1] - np.float32(K[3])) < 1e-4
+    un = oracle.undistort_keypoints(kps, K, D)
+    assert (un["octave"] == kps["octave"]).all() and (un["x"] != kps["x"]).any()
+    # forward model applied to the result returns the input (the five fixed-point iterations converge near the axis)
+    x = (np.float64(un["x"][1]) - K[2]) / K[0]
+    y = (np.float64(un["y"][1]) - K[3]) / K[1]
+    r2 = x * x + y * y
+    rad = 1 + D[0] * r2 + D[1] * r2 * r2 + D[4] * r2 ** 3
+    xd = x * rad + 2 * D[2] * x * y + D[3] * (r2 + 2 * x * x)
+    yd = y * rad + D[2] * (r2 + 2 * y * y) + 2 * D[3] * x * y
+    assert abs(xd * K[0] + K[2] - 320) < 1e-3 and abs(yd * K[1] + K[3] - 240) < 1e-3
+    # bounds: min of the left corners' x, max of the right corners' x, likewise for y
+    b = oracle.compute_image_bounds(640, 480, K, D)
+    c = oracle.undistort_points([[0, 0], [640, 0], [0, 480], [640, 480]], K, D)
+    assert b[0] == min(c[0, 0], c[2, 0]) and b[1] == max(c[1, 0], c[3, 0])
+    assert b[2] == min(c[0, 1], c[1, 1]) and b[3] == max(c[2, 1], c[3, 1])
