@@ -135,11 +135,15 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(const OrbGeom* _
                           xa + 4 * nd <= (level == 0 ? L.w : pitch);
     const int off = fastLoad ? tx0 - xa : 0;
     if (fastLoad) {
-        const uint8_t* src = img + (int64_t)(Y0 - 3) * pitch + xa;
-        const int total = th * nd;
-        for (int k = lane; k < total; k += 64) {
-            const int r = k / nd, d = k - r * nd;
-            *(uint32_t*)&tile[r * TILE_PITCH + 4 * d] = *(const uint32_t*)(src + (int64_t)r * pitch + 4 * d);
+        // lane = (row within a pass, dword); a pass covers 64 / nd rows (nd <= 18: at least 3)
+        const int rpp = 64 / nd;
+        const int rr = lane / nd, d = lane - rr * nd;
+        if (rr < rpp) {
+            const uint8_t* src = img + (int64_t)(Y0 - 3 + rr) * pitch + xa + 4 * d;
+            uint32_t* dst = (uint32_t*)&tile[rr * TILE_PITCH + 4 * d];
+            const int64_t srcStep = (int64_t)rpp * pitch;
+            const int dstStep = rpp * (TILE_PITCH / 4);
+            for (int r = rr; r < th; r += rpp, src += srcStep, dst += dstStep) *dst = *(const uint32_t*)src;
         }
     } else {
         const uint8_t* src = img + (int64_t)(Y0 - 3) * pitch + tx0;

@@ -49,7 +49,7 @@ static __device__ __forceinline__ int qt_level(const OrbGeom* g, const OrbLevel&
     return count;
 }
 
-__global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __restrict__ g, int frame0,
+__global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __restrict__ g, int frame0, int nframes,
                                                         const uint32_t* __restrict__ cellKeys,
                                                         const int* __restrict__ cellCount,
                                                         unsigned long long* __restrict__ sortBuf,
@@ -60,7 +60,8 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __re
     __shared__ QtShared sh;
     __shared__ unsigned long long s_keys[QT_LDS_KEYS];
     const int nlevels = g->nlevels;
-    const int level = blockIdx.x % nlevels, frame = frame0 + blockIdx.x / nlevels;
+    // level-major launch order: the levels with the most keys (the longest-running workgroups) start first
+    const int level = blockIdx.x / nframes, frame = frame0 + blockIdx.x % nframes;
     const OrbLevel& L = g->lv[level];
     const int t = threadIdx.x, T = (int)blockDim.x;
     unsigned long long* sortedG = sortBuf + ((int64_t)frame * g->keysPerFrame + L.keyBase) * 2;
@@ -141,7 +142,7 @@ int orb_launch_quadtree(const OrbBatch& b) {
     // large levels (4K frames hand ~1e5 keys to the quadtree) get a full 1024-thread workgroup
     const int threads = g.lv[0].keyCap > 400000 ? 1024 : 256;
     hipLaunchKernelGGL(k_quadtree, dim3(b.nframes * g.nlevels), dim3(threads), 0, (hipStream_t)b.stream, b.d_geom,
-                       b.frame0, b.d_cellKeys, b.d_cellCount, b.d_sort, b.d_nodes, b.d_ints, b.d_selXY, b.d_selScore, b.d_levelCount,
+                       b.frame0, b.nframes, b.d_cellKeys, b.d_cellCount, b.d_sort, b.d_nodes, b.d_ints, b.d_selXY, b.d_selScore, b.d_levelCount,
                        b.d_levelKeys, b.d_error);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
