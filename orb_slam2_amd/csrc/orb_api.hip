@@ -67,6 +67,29 @@ struct DevBuf {
     }
 };
 
+struct PinBuf {  // page-locked host staging: one DMA per direction instead of per-row / pageable copies
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return ORB_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipHostMalloc(&p, need, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            orb_set_error("hipHostMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+            return ORB_ERR_NOMEM;
+        }
+        bytes = need;
+        return ORB_OK;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
 #define ORB_MAX_PARTS 4
 #define ORB_MIN_PART_FRAMES 8   // groups smaller than this do not fill the device; the batch is then not split
 
@@ -89,6 +112,7 @@ struct orb_ctx {
     int parts = 3;
     DevBuf dGeom, dAreaTaps, dLinTaps, dInput, dPyr, dCellKeys, dCellCount, dSort, dNodes, dInts,
         dSelXY, dSelScore, dLevelCount, dLevelKeys, dError, dKps, dDesc, dNOut, dTmpA, dTmpB;
+    PinBuf pinIn, pinOut;  // host-pointer entry points only, sized on first use
     int lastFrames = 0;
     int inputStride = 0;
     const uint8_t* lastImg0 = nullptr;
@@ -516,6 +540,8 @@ extern "C" void orb_destroy(orb_ctx* c) {
                       &c->dLevelCount, &c->dLevelKeys, &c->dError, &c->dKps, &c->dDesc, &c->dNOut, &c->dTmpA,
                       &c->dTmpB};
     for (DevBuf* b : bufs) b->release();
+    c->pinIn.release();
+    c->pinOut.release();
     if (c->matchState) orb_match_state_free(c->matchState);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     for (int i = 0; i < ORB_MAX_PARTS - 1; i++) {
@@ -744,20 +770,37 @@ extern "C" int orb_extract_batch(orb_ctx* c, const uint8_t* const* imgs, int n, 
     const int cap = orb_max_keypoints_per_frame(c);
     const int dstride = c->inputStride;
     const int64_t fstride = (int64_t)dstride * h;
+    // frames -> page-locked staging in the device layout (row copies on the host), then one DMA
+    if ((rc = c->pinIn.ensure((size_t)n * fstride))) return rc;
     for (int f = 0; f < n; f++) {
         if (!imgs[f]) {
             orb_set_error("frame %d is null", f);
             return ORB_ERR_INVALID;
         }
-        HIP_TRY(hipMemcpy2DAsync((uint8_t*)c->dInput.p + f * fstride, dstride, imgs[f], stride, w, h,
-                                 hipMemcpyHostToDevice, c->stream));
+        uint8_t* dst = (uint8_t*)c->pinIn.p + f * fstride;
+        if (stride == dstride) {
+            memcpy(dst, imgs[f], (size_t)stride * (h - 1) + w);
+        } else {
+            for (int r = 0; r < h; r++) memcpy(dst + (size_t)r * dstride, imgs[f] + (size_t)r * stride, (size_t)w);
+        }
     }
+    HIP_TRY(hipMemcpyAsync(c->dInput.p, c->pinIn.p, (size_t)n * fstride, hipMemcpyHostToDevice, c->stream));
     rc = run_batch(c, (const uint8_t*)c->dInput.p, n, w, h, dstride, fstride, (orb_keypoint*)c->dKps.p,
                    (uint8_t*)c->dDesc.p, cap, (int*)c->dNOut.p, c->stream);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(n_out, c->dNOut.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    // everything back in one go: [error flag | counts | keypoints (cap per frame) | descriptors], one synchronisation
+    const size_t offCnt = 64, offKps = offCnt + (((size_t)n * 4 + 63) & ~(size_t)63);
+    const size_t offDesc = offKps + (size_t)n * cap * sizeof(orb_keypoint);
+    if ((rc = c->pinOut.ensure(offDesc + (size_t)n * cap * 32))) return rc;
+    uint8_t* po = (uint8_t*)c->pinOut.p;
+    HIP_TRY(hipMemcpyAsync(po, c->dError.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(po + offCnt, c->dNOut.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (kps)
+        HIP_TRY(hipMemcpyAsync(po + offKps, c->dKps.p, (size_t)n * cap * sizeof(orb_keypoint), hipMemcpyDeviceToHost, c->stream));
+    if (desc) HIP_TRY(hipMemcpyAsync(po + offDesc, c->dDesc.p, (size_t)n * cap * 32, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if ((rc = read_error_flag(c))) return rc;
+    if (*(const int*)po != 0) return read_error_flag(c);
+    memcpy(n_out, po + offCnt, (size_t)n * 4);
     for (int f = 0; f < n; f++) {
         const int m = n_out[f];
         if (m > cap_per_frame) {
@@ -766,14 +809,11 @@ extern "C" int orb_extract_batch(orb_ctx* c, const uint8_t* const* imgs, int n, 
         }
         if (m > 0) {
             if (kps)
-                HIP_TRY(hipMemcpyAsync(kps + (size_t)f * cap_per_frame, (orb_keypoint*)c->dKps.p + (size_t)f * cap,
-                                       (size_t)m * sizeof(orb_keypoint), hipMemcpyDeviceToHost, c->stream));
-            if (desc)
-                HIP_TRY(hipMemcpyAsync(desc + (size_t)f * cap_per_frame * 32, (uint8_t*)c->dDesc.p + (size_t)f * cap * 32,
-                                       (size_t)m * 32, hipMemcpyDeviceToHost, c->stream));
+                memcpy(kps + (size_t)f * cap_per_frame, po + offKps + (size_t)f * cap * sizeof(orb_keypoint),
+                       (size_t)m * sizeof(orb_keypoint));
+            if (desc) memcpy(desc + (size_t)f * cap_per_frame * 32, po + offDesc + (size_t)f * cap * 32, (size_t)m * 32);
         }
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
     return ORB_OK;
 }
 
