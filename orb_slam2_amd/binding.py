@@ -107,12 +107,13 @@ class Context:
         self.params = OrbParams(nfeatures, scale, nlevels, ini_th, min_th, max_width, max_height, max_batch, device, quirks)
         self.h = C.c_void_p()
         self.nlevels = nlevels
+        self._destroy = lib().orb_destroy  # kept on the object: module globals may be gone at interpreter exit
         _check(lib().orb_create(C.byref(self.params), C.byref(self.h)))
         self.cap = lib().orb_max_keypoints_per_frame(self.h)
 
     def close(self):
         if getattr(self, "h", None) and self.h:
-            lib().orb_destroy(self.h)
+            self._destroy(self.h)
             self.h = C.c_void_p()
 
     __del__ = close
@@ -288,12 +289,13 @@ class BruteForce:
     def __init__(self, device=0):
         self.h = C.c_void_p()
         self.device = device
+        self._destroy = lib().orb_bf_destroy
         _check(lib().orb_bf_create(device, C.byref(self.h)))
         self._keep = None
 
     def close(self):
         if getattr(self, "h", None) and self.h:
-            lib().orb_bf_destroy(self.h)
+            self._destroy(self.h)
             self.h = C.c_void_p()
 
     __del__ = close
