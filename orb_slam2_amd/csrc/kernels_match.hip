@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <cstring>
 #include <vector>
 
 #include "orb_internal.h"
@@ -631,6 +632,9 @@ struct MatchState {
     size_t capPairs = 0;    // pairs cellStart holds
     size_t capPairs1 = 0;   // npairs * stride1 the per-query arrays hold
     size_t capLists = 0;    // list entries
+    void* blockDev = nullptr;   // staging of the host-pointer entry points, see below
+    void* blockHost = nullptr;
+    size_t blockBytes = 0;
 };
 
 void orb_match_state_free(void* p) {
@@ -639,6 +643,8 @@ void orb_match_state_free(void* p) {
     void* bufs[] = {s->err, s->gSorted, s->gXY, s->gOct, s->cellStart, s->lists, s->counts, s->accepted, s->order, s->binOf};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    if (s->blockDev) (void)hipFree(s->blockDev);
+    if (s->blockHost) (void)hipHostFree(s->blockHost);
     delete s;
 }
 
@@ -791,24 +797,40 @@ extern "C" int orb_match_window_batch_device(orb_ctx* c, int npairs, const orb_k
     return check_match_launch();
 }
 
+// Host-pointer entry points: every input and output of a call is laid out in one block that exists
+// twice, in page-locked host memory and on the device (both grown on demand and kept).  A call packs
+// its inputs on the host, moves them with one DMA, runs the kernels, moves the outputs (and the error
+// flag) back with one DMA and synchronises once.
 namespace {
-struct Tmp {  // scoped device allocation for the host-pointer entry points
-    void* p = nullptr;
-    ~Tmp() {
-        if (p) (void)hipFree(p);
-    }
-    hipError_t put(const void* src, size_t bytes) {
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 4);
-        if (e == hipSuccess && src && bytes) e = hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
-        return e;
+struct Block {
+    size_t off = 0;
+    size_t add(size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
     }
 };
 }  // namespace
 
-static int read_match_error(MatchState* s, const char* what) {
-    int flag = 0;
-    HIP_TRY(hipMemcpy(&flag, s->err, 4, hipMemcpyDeviceToHost));
-    if (flag) {
+static int ensure_block(MatchState* s, size_t bytes) {
+    if (bytes <= s->blockBytes) return ORB_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    if (s->blockDev) (void)hipFree(s->blockDev);
+    if (s->blockHost) (void)hipHostFree(s->blockHost);
+    s->blockDev = s->blockHost = nullptr;
+    s->blockBytes = 0;
+    hipError_t e = hipMalloc(&s->blockDev, bytes);
+    if (e == hipSuccess) e = hipHostMalloc(&s->blockHost, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        orb_set_error("matcher staging (%zu bytes): %s", bytes, hipGetErrorString(e));
+        return ORB_ERR_NOMEM;
+    }
+    s->blockBytes = bytes;
+    return ORB_OK;
+}
+
+static int match_error(const int* flag, MatchState* s, const char* what) {
+    if (*flag) {
         HIP_TRY(hipMemset(s->err, 0, 4));
         orb_set_error("%s: keypoint count exceeds the kernel's limits", what);
         return ORB_ERR_CAPACITY;
@@ -827,27 +849,41 @@ extern "C" int orb_match_window(orb_ctx* c, const orb_keypoint* k1, const uint8_
     *nmatches = 0;
     if (n1 == 0) return ORB_OK;
     HIP_TRY(hipSetDevice(orb_ctx_device(c)));
-    Tmp tk1, td1, tk2, td2, tn, tprev, tm, tnm;
-    const int ns[2] = {n1, n2};
     const int s1 = n1, s2 = n2 > 0 ? n2 : 1;
-    HIP_TRY(tk1.put(k1, (size_t)n1 * sizeof(orb_keypoint)));
-    HIP_TRY(td1.put(d1, (size_t)n1 * 32));
-    HIP_TRY(tk2.put(k2, (size_t)n2 * sizeof(orb_keypoint)));
-    HIP_TRY(td2.put(d2, (size_t)n2 * 32));
-    HIP_TRY(tn.put(ns, sizeof(ns)));
-    HIP_TRY(tprev.put(prev_xy, (size_t)n1 * 8));
-    HIP_TRY(tm.put(nullptr, (size_t)n1 * 4));
-    HIP_TRY(tnm.put(nullptr, 4));
-    int rc = orb_match_window_batch_device(c, 1, (const orb_keypoint*)tk1.p, (const uint8_t*)td1.p, (const int*)tn.p, s1,
-                                           (const orb_keypoint*)tk2.p, (const uint8_t*)td2.p, (const int*)tn.p + 1, s2,
-                                           img_w, img_h, (float*)tprev.p, (int*)tm.p, window, nnratio, check_ori,
-                                           (int*)tnm.p, nullptr);
+    MatchState* s = nullptr;
+    MatchBuffers B;
+    int rc = match_buffers(c, 1, s1, s2, &s, &B);  // (creates the state on first use)
     if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    if ((rc = read_match_error((MatchState*)*orb_ctx_match_state(c), "windowed matcher"))) return rc;
-    HIP_TRY(hipMemcpy(prev_xy, tprev.p, (size_t)n1 * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(matches12, tm.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(nmatches, tnm.p, 4, hipMemcpyDeviceToHost));
+    Block L;
+    const size_t oK1 = L.add((size_t)n1 * sizeof(orb_keypoint)), oD1 = L.add((size_t)n1 * 32);
+    const size_t oK2 = L.add((size_t)s2 * sizeof(orb_keypoint)), oD2 = L.add((size_t)s2 * 32), oN = L.add(8);
+    const size_t oPrev = L.add((size_t)n1 * 8);  // in and out
+    const size_t oM = L.add((size_t)n1 * 4), oNm = L.add(4), oErr = L.add(4);
+    if ((rc = ensure_block(s, L.off))) return rc;
+    uint8_t* h = (uint8_t*)s->blockHost;
+    uint8_t* d = (uint8_t*)s->blockDev;
+    memcpy(h + oK1, k1, (size_t)n1 * sizeof(orb_keypoint));
+    memcpy(h + oD1, d1, (size_t)n1 * 32);
+    if (n2 > 0) {
+        memcpy(h + oK2, k2, (size_t)n2 * sizeof(orb_keypoint));
+        memcpy(h + oD2, d2, (size_t)n2 * 32);
+    }
+    const int ns[2] = {n1, n2};
+    memcpy(h + oN, ns, 8);
+    memcpy(h + oPrev, prev_xy, (size_t)n1 * 8);
+    HIP_TRY(hipMemcpyAsync(d, h, oM, hipMemcpyHostToDevice, nullptr));
+    rc = orb_match_window_batch_device(c, 1, (const orb_keypoint*)(d + oK1), d + oD1, (const int*)(d + oN), s1,
+                                       (const orb_keypoint*)(d + oK2), d + oD2, (const int*)(d + oN) + 1, s2, img_w, img_h,
+                                       (float*)(d + oPrev), (int*)(d + oM), window, nnratio, check_ori, (int*)(d + oNm),
+                                       nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d + oErr, s->err, 4, hipMemcpyDeviceToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(h + oPrev, d + oPrev, L.off - oPrev, hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    if ((rc = match_error((const int*)(h + oErr), s, "windowed matcher"))) return rc;
+    memcpy(prev_xy, h + oPrev, (size_t)n1 * 8);
+    memcpy(matches12, h + oM, (size_t)n1 * 4);
+    memcpy(nmatches, h + oNm, 4);
     return ORB_OK;
 }
 
@@ -876,38 +912,49 @@ extern "C" int orb_match_projected(orb_ctx* c, const float* u, const float* v, c
     MatchBuffers B;
     int rc = match_buffers(c, 1, nq, n2, &s, &B);
     if (rc) return rc;
-    Tmp tu, tv, tr, tl0, tl1, ta, tq, to, tk2, td2, tocc, tm, tnm;
-    HIP_TRY(tu.put(u, (size_t)nq * 4));
-    HIP_TRY(tv.put(v, (size_t)nq * 4));
-    HIP_TRY(tr.put(radius, (size_t)nq * 4));
-    HIP_TRY(tl0.put(min_level, (size_t)nq * 4));
-    HIP_TRY(tl1.put(max_level, (size_t)nq * 4));
-    HIP_TRY(ta.put(qangle, (size_t)nq * 4));
-    HIP_TRY(tq.put(qdesc, (size_t)nq * 32));
-    if (qobs) HIP_TRY(to.put(qobs, (size_t)nq));
-    HIP_TRY(tk2.put(k2, (size_t)n2 * sizeof(orb_keypoint)));
-    HIP_TRY(td2.put(d2, (size_t)n2 * 32));
-    if (occupied2) HIP_TRY(tocc.put(occupied2, (size_t)n2));
-    HIP_TRY(tm.put(nullptr, (size_t)n2 * 4));
-    HIP_TRY(tnm.put(nullptr, 4));
+    Block L;
+    const size_t oU = L.add((size_t)nq * 4), oV = L.add((size_t)nq * 4), oR = L.add((size_t)nq * 4);
+    const size_t oL0 = L.add((size_t)nq * 4), oL1 = L.add((size_t)nq * 4), oA = L.add((size_t)nq * 4);
+    const size_t oQ = L.add((size_t)nq * 32), oObs = L.add((size_t)nq);
+    const size_t oK2 = L.add((size_t)n2 * sizeof(orb_keypoint)), oD2 = L.add((size_t)n2 * 32), oOcc = L.add((size_t)n2);
+    const size_t oM = L.add((size_t)n2 * 4), oNm = L.add(4), oErr = L.add(4);  // outputs
+    if ((rc = ensure_block(s, L.off))) return rc;
+    uint8_t* h = (uint8_t*)s->blockHost;
+    uint8_t* d = (uint8_t*)s->blockDev;
+    memcpy(h + oU, u, (size_t)nq * 4);
+    memcpy(h + oV, v, (size_t)nq * 4);
+    memcpy(h + oR, radius, (size_t)nq * 4);
+    memcpy(h + oL0, min_level, (size_t)nq * 4);
+    memcpy(h + oL1, max_level, (size_t)nq * 4);
+    memcpy(h + oA, qangle, (size_t)nq * 4);
+    memcpy(h + oQ, qdesc, (size_t)nq * 32);
+    if (qobs) memcpy(h + oObs, qobs, (size_t)nq);
+    memcpy(h + oK2, k2, (size_t)n2 * sizeof(orb_keypoint));
+    memcpy(h + oD2, d2, (size_t)n2 * 32);
+    if (occupied2) memcpy(h + oOcc, occupied2, (size_t)n2);
     hipStream_t st = nullptr;
+    HIP_TRY(hipMemcpyAsync(d, h, oM, hipMemcpyHostToDevice, st));
     const GridGeom G = grid_geom(c, img_w, img_h);
-    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, st, (const orb_keypoint*)tk2.p, (const int*)nullptr, n2, n2,
+    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, st, (const orb_keypoint*)(d + oK2), (const int*)nullptr, n2, n2,
                        G, B, (int*)s->err);
     if ((rc = check_match_launch())) return rc;
     hipLaunchKernelGGL(k_match_lists<true>, dim3((nq + 3) / 4, 1), dim3(256), 0, st, (const orb_keypoint*)nullptr,
-                       (const uint8_t*)tq.p, (const int*)nullptr, nq, nq, (const float*)nullptr, 0.f, (const float*)tu.p,
-                       (const float*)tv.p, (const float*)tr.p, (const int*)tl0.p, (const int*)tl1.p,
-                       (const uint8_t*)td2.p, n2, G, orb_ctx_quirks(c), B);
+                       (const uint8_t*)(d + oQ), (const int*)nullptr, nq, nq, (const float*)nullptr, 0.f,
+                       (const float*)(d + oU), (const float*)(d + oV), (const float*)(d + oR), (const int*)(d + oL0),
+                       (const int*)(d + oL1), (const uint8_t*)(d + oD2), n2, G, orb_ctx_quirks(c), B);
     if ((rc = check_match_launch())) return rc;
     hipLaunchKernelGGL(k_match_resolve<true>, dim3(1), dim3(256), 0, st, (const orb_keypoint*)nullptr,
-                       (const int*)nullptr, nq, nq, (const orb_keypoint*)tk2.p, (const int*)nullptr, n2, n2,
-                       (float*)nullptr, (int*)nullptr, (uint8_t*)s->binOf, (const float*)ta.p, (const uint8_t*)to.p,
-                       (const uint8_t*)tocc.p, (int*)tm.p, 0.f, th_high, check_ori, B, (int*)tnm.p, (int*)s->err);
+                       (const int*)nullptr, nq, nq, (const orb_keypoint*)(d + oK2), (const int*)nullptr, n2, n2,
+                       (float*)nullptr, (int*)nullptr, (uint8_t*)s->binOf, (const float*)(d + oA),
+                       qobs ? (const uint8_t*)(d + oObs) : (const uint8_t*)nullptr,
+                       occupied2 ? (const uint8_t*)(d + oOcc) : (const uint8_t*)nullptr, (int*)(d + oM), 0.f, th_high,
+                       check_ori, B, (int*)(d + oNm), (int*)s->err);
     if ((rc = check_match_launch())) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    if ((rc = read_match_error(s, "projected matcher"))) return rc;
-    HIP_TRY(hipMemcpy(match2, tm.p, (size_t)n2 * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(nmatches, tnm.p, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(d + oErr, s->err, 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h + oM, d + oM, L.off - oM, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if ((rc = match_error((const int*)(h + oErr), s, "projected matcher"))) return rc;
+    memcpy(match2, h + oM, (size_t)n2 * 4);
+    memcpy(nmatches, h + oNm, 4);
     return ORB_OK;
 }
