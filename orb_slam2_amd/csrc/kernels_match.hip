@@ -441,8 +441,8 @@ __global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __res
     for (int p = t; p < nIn; p += 256) {
         const int i2 = (int)(gS[p] & 0xFFFFu);
         S.idx[p] = (uint16_t)i2;
-        if (PROJECTED) S.so[p] = occupied2 ? occupied2[i2] : 0;
-        else S.so[p] = 0xFFFFFFFFu;  // distance INT_MAX, owner -1
+        if (PROJECTED) S.so[p] = 0xFFFF0000u | (occupied2 ? occupied2[i2] : 0);  // owner -1
+        else S.so[p] = 0xFFFFFFFFu;                                            // distance INT_MAX, owner -1
     }
     if (t < ORB_HISTO) S.hist[t] = 0;
     if (t == 0) S.nmatches = 0;
@@ -513,6 +513,8 @@ __global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __res
             const int i1L = S.metaI1[buf][lane], cntL = S.metaCnt[buf][lane], obsL = S.metaObs[buf][lane];
             const int nHere = nActive - base < 64 ? nActive - base : 64;
             uint32_t e0 = S.tile[buf][0][lane], e1 = S.tile[buf][0][lane + 64];
+            int accL = -1;  // lane qq: keypoint the chunk's query qq was matched to
+#pragma nounroll
             for (int qq = 0; qq < nHere; qq++) {
                 const int i1 = __builtin_amdgcn_readlane(i1L, qq);
                 const int cnt = __builtin_amdgcn_readlane(cntL, qq);
@@ -533,10 +535,10 @@ __global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __res
                 if (lane < cnt) consider(e0);
                 if (lane + 64 < cnt) consider(e1);
                 for (int c = lane + 128; c < cnt; c += 64) consider(lists[(int64_t)i1 * B.capQ + c]);
-                e0 = n0;
-                e1 = n1;
                 if (PROJECTED) k1 = wave_min_u32(k1);
                 else wave_top2_u32(k1, k2);
+                e0 = n0;
+                e1 = n1;
                 if (k1 == 0xFFFFFFFFu) continue;  // nothing survived: bestDist stays at its initial value and fails the test
                 const int bestDist = (int)(k1 >> 16);
                 const int bestPos = (int)(k1 & 0xFFFFu);
@@ -549,30 +551,39 @@ __global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __res
                     accept = bestDist <= M_TH_LOW && (float)bestDist < __fmul_rn(bestDist2, nnratio);  // :78-80
                 }
                 if (accept) {
+                    // No global memory is touched here: the owner of every keypoint lives in LDS (vnMatches12 /
+                    // the map-point assignment follow from it after the loop), the acceptance in a register.
                     const int bestIdx2 = S.idx[bestPos];
-                    const int old = (int)(int16_t)(S.so[bestPos] >> 16);
-                    if (lane == 0) {
-                        if (PROJECTED) {
-                            match2[bestIdx2] = i1;
-                            S.so[bestPos] = (uint32_t)obs;
-                        } else {
-                            if (old >= 0) {  // :82-86
-                                m12[old] = -1;
-                                nmatches--;
-                            }
-                            m12[i1] = bestIdx2;
-                            S.so[bestPos] = (uint32_t)bestDist | ((uint32_t)i1 << 16);
-                        }
-                        accepted[i1] = bestIdx2;
-                        nmatches++;
-                    }
+                    if (lane == qq) accL = bestIdx2;
+                    if (lane == 0) S.so[bestPos] = (PROJECTED ? (uint32_t)obs : (uint32_t)bestDist) | ((uint32_t)i1 << 16);
+                    nmatches++;
                     wave_lds_order();
                 }
             }
+            if (lane < nHere) accepted[i1L] = accL;
         }
         __syncthreads();
     }
-    if (t == 0) S.nmatches = nmatches;
+    // vnMatches12 (window search): query i1 holds keypoint i2 exactly when i2's owner is i1 at the end, a
+    // stolen match having lost its owner (:82-86).  Projected search: the keypoint holds the map point of
+    // its last owner; every acceptance counts (:364-366).
+    if (t == 0) S.nmatches = PROJECTED ? nmatches : 0;
+    __threadfence_block();
+    __syncthreads();
+    {
+        int mine = 0;
+        for (int p = t; p < nIn; p += 256) {
+            const int own = (int)(int16_t)(S.so[p] >> 16);
+            if (own < 0) continue;
+            if (PROJECTED) {
+                match2[S.idx[p]] = own;
+            } else {
+                m12[own] = S.idx[p];
+                mine++;
+            }
+        }
+        if (!PROJECTED && mine) atomicAdd(&S.nmatches, mine);
+    }
     __threadfence_block();
     __syncthreads();
     nmatches = S.nmatches;
