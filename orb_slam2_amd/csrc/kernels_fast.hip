@@ -36,8 +36,18 @@ static __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-static __device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b, c)); }
-static __device__ __forceinline__ int imax3(int a, int b, int c) { return max(a, max(b, c)); }
+// Three-input minimum / maximum as single instructions.  Written as min(a, min(b, c)) the compiler shares
+// the inner two-input results between neighbouring arcs and ends up with twice as many instructions.
+static __device__ __forceinline__ int imin3(int a, int b, int c) {
+    int r;
+    asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+static __device__ __forceinline__ int imax3(int a, int b, int c) {
+    int r;
+    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 // t* = max(A, B) - 1 with A = max over the 16 arcs of 9 contiguous ring pixels
 // of min(v - ring), B likewise for (ring - v)   (cv::cornerScore<16>).
@@ -67,12 +77,17 @@ static __device__ __forceinline__ int fast_score(const uint8_t* c) {
         lo3[k] = imin3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
         hi3[k] = imax3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
     }
-    int A = -256, Bn = 256;  // Bn = min over arcs of max(d) = -B
+    int a9[16], b9[16];  // min / max over the arc of 9 starting at k
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        A = max(A, imin3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]));
-        Bn = min(Bn, imax3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]));
+        a9[k] = imin3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+        b9[k] = imax3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
     }
+    // A = max over arcs of min(d), Bn = min over arcs of max(d) = -B: 16 -> 6 -> 2 -> 1
+    const int A = max(imax3(imax3(a9[0], a9[1], a9[2]), imax3(a9[3], a9[4], a9[5]), imax3(a9[6], a9[7], a9[8])),
+                      imax3(imax3(a9[9], a9[10], a9[11]), imax3(a9[12], a9[13], a9[14]), a9[15]));
+    const int Bn = min(imin3(imin3(b9[0], b9[1], b9[2]), imin3(b9[3], b9[4], b9[5]), imin3(b9[6], b9[7], b9[8])),
+                       imin3(imin3(b9[9], b9[10], b9[11]), imin3(b9[12], b9[13], b9[14]), b9[15]));
     return max(A, -Bn) - 1;
 }
 
