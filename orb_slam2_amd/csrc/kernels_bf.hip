@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_bf_top2(const uint32_t* __restrict__ q,
                                                  const uint32_t* __restrict__ db, long long nd,
                                                  long long rowsPerChunk, long long globalBase,
                                                  unsigned long long* __restrict__ partial) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long qb = ((long long)blockIdx.x * 4 + wave) * (64 * QPL);
     if (qb >= nq) return;
     uint32_t qv[QPL][8];
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void k_bf_top2_lds(const uint32_t* __restrict_
     static_assert(TR * 32 % (256 * 16) == 0, "tile must be a whole number of 16-byte loads per thread");
     constexpr int LPT = TR * 32 / (256 * 16);  // 16-byte loads per thread and tile
     __shared__ __attribute__((aligned(16))) uint32_t s_rows[2][TR * 8];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     long long qb = ((long long)blockIdx.x * 4 + wave) * (64 * QPL);
     const bool active = qb < nq;   // inactive waves still help loading tiles and hit every barrier
     if (!active) qb = 0;

@@ -138,7 +138,9 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     __shared__ __attribute__((aligned(16))) uint8_t s_raw[DESC_WAVES][RAW_N * RAW_P];
     __shared__ __attribute__((aligned(16))) uint16_t s_hb[DESC_WAVES][RAW_N * HB_P];
     __shared__ __attribute__((aligned(16))) uint8_t s_bl[DESC_WAVES][BL_N * BL_P];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wavefront index is the same in all 64 lanes: telling the compiler so keeps everything derived from
+    // it (frame, level, keypoint, window addresses, loop bounds) in scalar registers
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int outCapFrame = g->outCapFrame, nlevels = g->nlevels;
     const int64_t slotLocal = (int64_t)blockIdx.x * DESC_WAVES + wave;
     if (slotLocal >= (int64_t)nframes * outCapFrame) return;

@@ -101,7 +101,9 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(const OrbGeom* _
     __shared__ __attribute__((aligned(16))) uint8_t s_score[FAST_WAVES][SCORE_ROWS * SCORE_PITCH];
     __shared__ uint16_t s_cand[FAST_WAVES][128];
     __shared__ uint16_t s_corn[FAST_WAVES][CORN_CAP];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wavefront index is the same in all 64 lanes: telling the compiler so keeps everything derived from
+    // it (frame, level, cell geometry, loop bounds) in scalar registers
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int64_t cellLocal = (int64_t)blockIdx.x * FAST_WAVES + wave;
     const int cellsPerFrame = g->cellsPerFrame;
     if (cellLocal >= (int64_t)nframes * cellsPerFrame) return;  // whole wave leaves; no workgroup barrier below

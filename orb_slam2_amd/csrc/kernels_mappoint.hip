@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64 * MP_WAVES) void k_distinctive(const uint8_t* __
                                                               int selfDistance, int* __restrict__ bestIndex,
                                                               int* __restrict__ bestMedian) {
     __shared__ __attribute__((aligned(16))) uint32_t s_desc[MP_WAVES][MP_LDS_DESC * 8];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // uniform per wavefront
     const int pt = blockIdx.x * MP_WAVES + wave;
     if (pt >= npoints) return;
     const int lo = offsets[pt], N = offsets[pt + 1] - lo;

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void k_match_lists(const orb_keypoint* __restr
                                                      const uint8_t* __restrict__ d2all, int stride2, GridGeom G,
                                                      unsigned quirks, MatchBuffers B) {
     const int pair = blockIdx.y, lane = threadIdx.x & 63;
-    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int q = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform per wavefront
     const int nq = PROJECTED ? nqConst : n1s[pair];
     if (q >= nq || q >= stride1) return;
     int* counts = B.counts + (int64_t)pair * stride1;
