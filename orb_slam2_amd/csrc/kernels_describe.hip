@@ -23,7 +23,8 @@
 #define BL_N 37
 #define BL_P 44
 
-__constant__ signed char c_pattern[256 * 4] = {
+// the 256 test pairs (x0, y0, x1, y1) of src/ORBextractor.cc:105-362, kept as floats for the rotation
+__constant__ __attribute__((aligned(16))) float c_pattern[256 * 4] = {
 #include "orb_pattern.inc"
 };
 
@@ -119,10 +120,20 @@ static __device__ __forceinline__ uint32_t dot4_u8(uint32_t a, uint32_t b, uint3
     return __builtin_amdgcn_udot4(a, b, c, false);
 }
 
+// Sum over the 64 lanes, returned to all of them: prefix sums inside each row of 16 lanes and two row
+// broadcasts through the DPP path (lanes a step does not feed add 0), then a read of lane 63.
+template <int CTRL, int ROWS>
+static __device__ __forceinline__ int dpp_add_step(int v) {
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, 0xf, false);
+}
 static __device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = dpp_add_step<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_add_step<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_add_step<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_add_step<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row's sum
+    v = dpp_add_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __restrict__ g,
@@ -220,20 +231,27 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     {
         // rows v = -15..15, aligned column groups 1..9 (they cover u = -15..15 for every `off`)
         const uint32_t* raw32 = (const uint32_t*)s_raw[wave];
-        for (int k = lane; k < 31 * 9; k += 64) {
-            const int r = k / 9, q = 1 + (k - r * 9);
-            const int v = r - 15, av = v < 0 ? -v : v;
-            const int lim = (int)((um >> (4 * av)) & 15ull);
-            const uint32_t w = raw32[(6 + r) * (RAW_P / 4) + q];
-            const int u0 = 4 * q - off - 21;  // u of the dword's first byte
-            // bytes lo..hi of the dword lie inside the patch row (|u| <= lim)
-            const int lo = max(0, -lim - u0), hi = min(3, lim - u0);
-            if (lo <= hi) {
-                const uint32_t ones = (0x01010101u << (8 * lo)) & (0x01010101u >> (8 * (3 - hi)));
-                const uint32_t idx = (ones * 0xffu) & 0x03020100u;
-                const int rowSum = (int)dot4_u8(w, ones, 0u);
-                m10 += u0 * rowSum + (int)dot4_u8(w, idx, 0u);
-                m01 += v * rowSum;
+        // lane = (row within a pass of seven, dword group 1..9); five passes cover the 31 rows
+        const int rr = lane / 9, q = 1 + (lane - rr * 9);
+        const int u0 = 4 * q - off - 21;  // u of the dword's first byte
+        if (rr < 7) {
+#pragma unroll
+            for (int it = 0; it < 5; it++) {
+                const int r = rr + 7 * it;
+                if (r < 31) {
+                    const int v = r - 15, av = v < 0 ? -v : v;
+                    const int lim = (int)((um >> (4 * av)) & 15ull);
+                    const uint32_t w = raw32[(6 + r) * (RAW_P / 4) + q];
+                    // bytes lo..hi of the dword lie inside the patch row (|u| <= lim)
+                    const int lo = max(0, -lim - u0), hi = min(3, lim - u0);
+                    if (lo <= hi) {
+                        const uint32_t ones = (0x01010101u << (8 * lo)) & (0x01010101u >> (8 * (3 - hi)));
+                        const uint32_t idx = (ones * 0xffu) & 0x03020100u;
+                        const int rowSum = (int)dot4_u8(w, ones, 0u);
+                        m10 += u0 * rowSum + (int)dot4_u8(w, idx, 0u);
+                        m01 += v * rowSum;
+                    }
+                }
             }
         }
     }
@@ -251,51 +269,61 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     const uint32_t wB = k2 | (k1 << 8) | (k0 << 16);               // taps 4..6
     const uint32_t* raw32 = (const uint32_t*)s_raw[wave];
     uint32_t* hb32 = (uint32_t*)hb;
-    for (int k = lane; k < RAW_N * HGROUPS; k += 64) {
-        const int r = k / HGROUPS, q = k - r * HGROUPS;
-        const uint32_t* p = raw32 + r * (RAW_P / 4) + q;
-        const uint32_t A = p[q > 0 ? -1 : 0], B = p[0], C = p[1];
-        // output m of the group sums bytes m-3 .. m+3 around column 4q + m: two unaligned dwords each
-        const uint32_t o0 = dot4_u8(__builtin_amdgcn_alignbyte(B, A, 1), wA, dot4_u8(__builtin_amdgcn_alignbyte(C, B, 1), wB, 0u));
-        const uint32_t o1 = dot4_u8(__builtin_amdgcn_alignbyte(B, A, 2), wA, dot4_u8(__builtin_amdgcn_alignbyte(C, B, 2), wB, 0u));
-        const uint32_t o2 = dot4_u8(__builtin_amdgcn_alignbyte(B, A, 3), wA, dot4_u8(__builtin_amdgcn_alignbyte(C, B, 3), wB, 0u));
-        const uint32_t o3 = dot4_u8(B, wA, dot4_u8(C, wB, 0u));
-        uint2 o;
-        o.x = (o0 & 0xffffu) | (o1 << 16);  // 16-bit wrap-around as in the 8.8 fixed-point row filter (sums stay below 2^16 anyway)
-        o.y = (o2 & 0xffffu) | (o3 << 16);
-        *(uint2*)(hb32 + r * (HB_P / 2) + 2 * q) = o;
+    // lane = (row within a pass of five, group of four columns); lanes 55..63 idle
+    const int rr = lane / HGROUPS, q = lane - rr * HGROUPS;
+    if (rr < 5) {
+        const uint32_t* p = raw32 + rr * (RAW_P / 4) + q;
+        uint32_t* dsth = hb32 + rr * (HB_P / 2) + 2 * q;
+        const int back = q > 0 ? -1 : 0;
+#pragma unroll
+        for (int it = 0; it < 9; it++, p += 5 * (RAW_P / 4), dsth += 5 * (HB_P / 2)) {
+            if (rr + 5 * it < RAW_N) {
+                const uint32_t A = p[back], B = p[0], C = p[1];
+                // output m of the group sums bytes m-3 .. m+3 around column 4q + m: two unaligned dwords each
+                const uint32_t o0 = dot4_u8(__builtin_amdgcn_alignbyte(B, A, 1), wA, dot4_u8(__builtin_amdgcn_alignbyte(C, B, 1), wB, 0u));
+                const uint32_t o1 = dot4_u8(__builtin_amdgcn_alignbyte(B, A, 2), wA, dot4_u8(__builtin_amdgcn_alignbyte(C, B, 2), wB, 0u));
+                const uint32_t o2 = dot4_u8(__builtin_amdgcn_alignbyte(B, A, 3), wA, dot4_u8(__builtin_amdgcn_alignbyte(C, B, 3), wB, 0u));
+                const uint32_t o3 = dot4_u8(B, wA, dot4_u8(C, wB, 0u));
+                uint2 o;
+                o.x = (o0 & 0xffffu) | (o1 << 16);  // (sums stay below 2^16)
+                o.y = (o2 & 0xffffu) | (o3 << 16);
+                *(uint2*)dsth = o;
+            }
+        }
     }
     wave_lds_sync();
     uint32_t* bl32 = (uint32_t*)bl;
     const uint32_t wP0 = k0 | (k1 << 16), wP1 = k2 | (k3 << 16), wP2 = k2 | (k1 << 16);  // row pairs (0,1) (2,3) (4,5)
-    for (int k = lane; k < BL_N * HGROUPS; k += 64) {
-        const int r = k / HGROUPS, q = k - r * HGROUPS;
-        const uint32_t* p = hb32 + r * (HB_P / 2) + 2 * q;
-        uint2 h[7];
+    if (rr < 5) {
+#pragma unroll 1
+        for (int r = rr; r < BL_N; r += 5) {
+            const uint32_t* p = hb32 + r * (HB_P / 2) + 2 * q;
+            uint2 h[7];
 #pragma unroll
-        for (int i = 0; i < 7; i++) h[i] = *(const uint2*)(p + i * (HB_P / 2));
-        uint32_t packed = 0;
+            for (int i = 0; i < 7; i++) h[i] = *(const uint2*)(p + i * (HB_P / 2));
+            uint32_t packed = 0;
 #pragma unroll
-        for (int half = 0; half < 2; half++) {  // dword `half` holds columns 2*half and 2*half + 1
-            uint32_t hw[7];
+            for (int half = 0; half < 2; half++) {  // dword `half` holds columns 2*half and 2*half + 1
+                uint32_t hw[7];
 #pragma unroll
-            for (int i = 0; i < 7; i++) hw[i] = half ? h[i].y : h[i].x;
+                for (int i = 0; i < 7; i++) hw[i] = half ? h[i].y : h[i].x;
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
-                // (row i, row i+1) of one column side by side; the seventh row is weighted inside its own dword
-                const uint32_t sel = c ? 0x07060302u : 0x05040100u;
-                const uint32_t p01 = __builtin_amdgcn_perm(hw[1], hw[0], sel);
-                const uint32_t p23 = __builtin_amdgcn_perm(hw[3], hw[2], sel);
-                const uint32_t p45 = __builtin_amdgcn_perm(hw[5], hw[4], sel);
-                uint32_t v = dot2_u16(hw[6], c ? (k0 << 16) : k0, 32768u);
-                v = dot2_u16(p45, wP2, v);
-                v = dot2_u16(p23, wP1, v);
-                v = dot2_u16(p01, wP0, v);
-                v >>= 16;
-                packed |= (v > 255u ? 255u : v) << (8 * (2 * half + c));
+                for (int c = 0; c < 2; c++) {
+                    // (row i, row i+1) of one column side by side; the seventh row is weighted inside its own dword
+                    const uint32_t sel = c ? 0x07060302u : 0x05040100u;
+                    const uint32_t p01 = __builtin_amdgcn_perm(hw[1], hw[0], sel);
+                    const uint32_t p23 = __builtin_amdgcn_perm(hw[3], hw[2], sel);
+                    const uint32_t p45 = __builtin_amdgcn_perm(hw[5], hw[4], sel);
+                    uint32_t v = dot2_u16(hw[6], c ? (k0 << 16) : k0, 32768u);
+                    v = dot2_u16(p45, wP2, v);
+                    v = dot2_u16(p23, wP1, v);
+                    v = dot2_u16(p01, wP0, v);
+                    v >>= 16;
+                    packed |= (v > 255u ? 255u : v) << (8 * (2 * half + c));
+                }
             }
+            bl32[r * (BL_P / 4) + q] = packed;
         }
-        bl32[r * (BL_P / 4) + q] = packed;
     }
     wave_lds_sync();
     bl += off + 3;  // blurred window pixel (r, c), c = 0..36, is bl[r * BL_P + c] from here on
@@ -308,8 +336,8 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int pair = 64 * r + lane;
-        const float x0 = (float)c_pattern[4 * pair + 0], y0 = (float)c_pattern[4 * pair + 1];
-        const float x1 = (float)c_pattern[4 * pair + 2], y1 = (float)c_pattern[4 * pair + 3];
+        const float4 pt = ((const float4*)c_pattern)[pair];
+        const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
         const int dy0 = (int)rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
         const int dx0 = (int)rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int dy1 = (int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
