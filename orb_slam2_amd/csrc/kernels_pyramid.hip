@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
     const int t = threadIdx.x;
     const int x0 = blockIdx.x * ORB_RS_TW, y0 = blockIdx.y * ORB_RS_TH;
     const int x1 = min(x0 + ORB_RS_TW, dw), y1 = min(y0 + ORB_RS_TH, dh);
-    const int dx = t & 63, q = t >> 6;
+    const int dx = t & 63, q = __builtin_amdgcn_readfirstlane(t >> 6);  // wavefront index: uniform
     const bool colValid = x0 + dx < dw;
     OrbAreaTap txa = {};
     OrbLinTap txl = {};
@@ -55,20 +55,25 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
     const int nd = (sx1 - sxa + 4) >> 2, nrows = sy1 - sy0 + 1;
     const uint8_t* S = src + (int64_t)blockIdx.z * sFrame;
     const bool aligned = (sstride & 3) == 0 && (((unsigned long long)S) & 3ull) == 0;
-    for (int k = t; k < nrows * nd; k += 256) {
-        const int r = k / nd, d = k - r * nd;
+    {   // thread = (row within a pass, dword); a pass covers 256 / nd rows
+        const int rpp = 256 / nd;  // nd <= 256: checked by the launcher
+        const int rr = t / nd, d = t - rr * nd;
         const int col = sxa + 4 * d;
-        const uint8_t* p = S + (int64_t)(sy0 + r) * sstride + col;
-        uint32_t v;
-        if (aligned && col + 3 < sw) {
-            v = *(const uint32_t*)p;
-        } else {
-            v = 0u;
+        if (rr < rpp) {
+            for (int r = rr; r < nrows; r += rpp) {
+                const uint8_t* p = S + (int64_t)(sy0 + r) * sstride + col;
+                uint32_t v;
+                if (aligned && col + 3 < sw) {
+                    v = *(const uint32_t*)p;
+                } else {
+                    v = 0u;
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                if (col + i < sw) v |= (uint32_t)p[i] << (8 * i);
+                    for (int i = 0; i < 4; i++)
+                        if (col + i < sw) v |= (uint32_t)p[i] << (8 * i);
+                }
+                *(uint32_t*)&tile[r * tp + 4 * d] = v;
+            }
         }
-        *(uint32_t*)&tile[r * tp + 4 * d] = v;
     }
     __syncthreads();
     // horizontal pass: column dx of every staged row (wave q takes rows q, q + 4, ...)
@@ -192,7 +197,7 @@ static int launch_resize(bool area, const uint8_t* src, int sw, int sh, int sstr
     orb_resize_tile_extent(sw, dw, scaleX, ORB_RS_TW, true, &tp);
     orb_resize_tile_extent(sh, dh, scaleY, ORB_RS_TH, false, &rows);
     const size_t lds = ORB_RS_TAP_BYTES + (((size_t)tp * rows + 15) & ~(size_t)15) + (size_t)rows * ORB_RS_TW * 4;
-    if (lds > 64 * 1024) {
+    if (lds > 64 * 1024 || tp / 4 > 256) {  // (the kernel stages one tile row with at most 256 threads)
         orb_set_error("resize %dx%d -> %dx%d: source tile of %zu bytes does not fit the kernel's LDS budget", sw, sh, dw,
                       dh, lds);
         return ORB_ERR_UNSUPPORTED;
