@@ -215,14 +215,12 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(const OrbGeom* _
         const uint8_t* c = &tile[(ly + 3) * TILE_PITCH + lx + 3];
         int y = ly;
         for (int p = 0; p < steps; p++, y += rowsPerStep, c += rowsPerStep * TILE_PITCH) {
-            bool pass = false;
-            if (xin && y < ch) {
-                const int v = c[0];
-                const int dS = v - c[3 * TILE_PITCH], dE = v - c[3], dN = v - c[-3 * TILE_PITCH], dW = v - c[-3];
-                const int hiV = min(max(dS, dN), max(dE, dW));  // > minTh: an adjacent compass pair is darker
-                const int loV = max(min(dS, dN), min(dE, dW));  // < -minTh: an adjacent compass pair is brighter
-                pass = hiV > minTh || loV < -minTh;
-            }
+            // (lanes outside the cell read tile bytes that belong to no pixel of it; their result is masked)
+            const int v = c[0];
+            const int dS = v - c[3 * TILE_PITCH], dE = v - c[3], dN = v - c[-3 * TILE_PITCH], dW = v - c[-3];
+            const int hiV = min(max(dS, dN), max(dE, dW));  // > minTh: an adjacent compass pair is darker
+            const int loV = max(min(dS, dN), min(dE, dW));  // < -minTh: an adjacent compass pair is brighter
+            const bool pass = xin & (y < ch) & ((hiV > minTh) | (loV < -minTh));
             const unsigned long long m = __ballot(pass);
             if (pass) cand[(tail + __popcll(m & below)) & 127] = (uint16_t)(lx | (y << 8));
             tail += __popcll(m);
