@@ -4,18 +4,21 @@
 //
 // One wavefront owns one 30-pixel-class cell.  The reference runs cv::FAST on
 // the cell's ROI with iniThFAST and, if that finds nothing, again with
-// minThFAST.  cv::FAST's corner score is the largest threshold at which the
-// pixel is still a corner, independent of the threshold it was called with, and
-// its non-maximum suppression only sees scores inside the ROI's interior.  So
-// one score map t* per cell serves both calls:
-//   corner@th  <=>  t* >= th
-//   kept@th    <=>  t* >= th  and  t* > t*(q) for the 8 neighbours q inside the interior
+// minThFAST; the kernel does the same, at most two attempts per cell.  cv::FAST's
+// corner score is the largest threshold at which the pixel is still a corner,
+// independent of the threshold it was called with, and its non-maximum
+// suppression only sees scores inside the ROI's interior, non-corners counting
+// as 0.  So, per attempt with threshold th, with t* the score:
+//   corner  <=>  t* >= th
+//   kept    <=>  t* >= th  and  t* > t*(q) for the 8 neighbours q that are corners
 // and the interiors of the cells tile the level without overlap.
 //
-// Steps per cell: (1) stage the interior + 3-pixel halo in LDS, (2) t* for every
-// interior pixel into an LDS score tile with a zero rim, (3) local-maximum test,
-// ballot + prefix popcount for row-major ordered compaction (the order cv::FAST
-// emits), with the ini/min choice made after counting.
+// Steps per cell: (1) stage the interior + 3-pixel halo in LDS; per attempt
+// (2) a cheap necessary test on every interior pixel queues candidates, which
+// get their score t* 64 at a time into an LDS score tile with a zero rim and
+// are listed when they are corners, (3) local-maximum test over the listed
+// corners, ballot + prefix popcount for row-major ordered compaction (the order
+// cv::FAST emits).
 #include <hip/hip_runtime.h>
 
 #include "orb_internal.h"
@@ -175,10 +178,14 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(const OrbGeom* _
     }
     wave_lds_sync();
 
-    // (2) scores.  Cells up to 32 wide are walked two rows per step.  A pixel can only reach t* >= minTh
-    // if two adjacent compass points of its ring (any arc of 9 holds such a pair) both differ from the
-    // centre by more than minTh with the same sign; pixels passing that test are queued in a small LDS
-    // ring, in row-major order, and scored 64 at a time.  Everything else keeps the score 0.
+    // (2)+(3) as the reference does it (src/ORBextractor.cc:846-858): first with iniThFAST, and only when
+    // that keeps nothing again with minThFAST.  Cells up to 32 wide are walked two rows per step.  A pixel
+    // can only reach t* >= th if two adjacent compass points of its ring (any arc of 9 holds such a pair)
+    // both differ from the centre by more than th with the same sign; pixels passing that test are queued
+    // in a small LDS ring, in row-major order, and scored 64 at a time; the others keep the score 0, which
+    // is what cv::FAST's suppression sees for non-corners.  Corners go to a list in row-major order; local
+    // maxima are taken over that list (bit k of a lane's mask remembers chunk k), or, in a cell with more
+    // corners than the list holds, over all its pixels (bit p remembers step p).
     const int minTh = g->minTh, iniTh = g->iniTh;
     const int two = cw <= 32;
     const int ly = two ? (lane >> 5) : 0, lx = two ? (lane & 31) : lane;
@@ -187,102 +194,98 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(const OrbGeom* _
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint16_t* cand = s_cand[wave];
     uint16_t* corn = s_corn[wave];
-    int head = 0, tail = 0;  // wave-uniform ring positions, tail - head <= 127
-    int nCorn = 0;           // corners found (t* >= minTh); the first CORN_CAP are listed, in row-major order
-    // scores 64 queued candidates (lanes below `count`), marks corners in the score tile and the list
-    auto score_chunk = [&](int count) {
-        wave_lds_sync();
-        bool corner = false;
-        unsigned q = 0;
-        int t = 0;
-        if (lane < count) {
-            q = cand[(head + lane) & 127];
-            const int qx = q & 255, qy = q >> 8;
-            t = fast_score(&tile[(qy + 3) * TILE_PITCH + qx + 3]);
-            corner = t >= minTh;
-            if (corner) score[(qy + 1) * SCORE_PITCH + qx + 1] = (uint8_t)t;
-        }
-        const unsigned long long m = __ballot(corner);
-        if (corner) {
-            const int pos = nCorn + __popcll(m & below);
-            if (pos < CORN_CAP) corn[pos] = (uint16_t)q;
-        }
-        nCorn += __popcll(m);
-        head += count;
-    };
-    {
-        const bool xin = lx < cw;
-        const uint8_t* c = &tile[(ly + 3) * TILE_PITCH + lx + 3];
-        int y = ly;
-        for (int p = 0; p < steps; p++, y += rowsPerStep, c += rowsPerStep * TILE_PITCH) {
-            // (lanes outside the cell read tile bytes that belong to no pixel of it; their result is masked)
-            const int v = c[0];
-            const int dS = v - c[3 * TILE_PITCH], dE = v - c[3], dN = v - c[-3 * TILE_PITCH], dW = v - c[-3];
-            const int hiV = min(max(dS, dN), max(dE, dW));  // > minTh: an adjacent compass pair is darker
-            const int loV = max(min(dS, dN), min(dE, dW));  // < -minTh: an adjacent compass pair is brighter
-            const bool pass = xin & (y < ch) & ((hiV > minTh) | (loV < -minTh));
-            const unsigned long long m = __ballot(pass);
-            if (pass) cand[(tail + __popcll(m & below)) & 127] = (uint16_t)(lx | (y << 8));
-            tail += __popcll(m);
-            if (tail - head >= 64) score_chunk(64);
-        }
-    }
-    if (tail > head) score_chunk(tail - head);
-    wave_lds_sync();
-
-    // (3) local maxima, counted for both thresholds, then the kept keys in row-major order.  With few
-    // corners the listed ones are visited (bit k of a lane's mask remembers chunk k); a cell with more
-    // corners than the list holds walks all its pixels instead (bit p remembers step p).
     const int cellCap = g->cellCap;
     uint32_t* out = cellKeys + cellGlobal * cellCap;
-    unsigned long long keepIni = 0ull, keepMin = 0ull;
-    int cntIni = 0, cntMin = 0;
-    const bool listed = nCorn <= CORN_CAP;
-    const int rounds = listed ? (nCorn + 63) >> 6 : steps;
-    for (int p = 0; p < rounds; p++) {
-        bool lm = false, li = false;
-        int px = lx, py = p * rowsPerStep + ly;
-        bool in = lx < cw && py < ch;
-        if (listed) {
-            in = p * 64 + lane < nCorn;
-            const unsigned q = in ? corn[p * 64 + lane] : 0u;
-            px = q & 255;
-            py = q >> 8;
-        }
-        if (in) {
-            const uint8_t* sp = &score[(py + 1) * SCORE_PITCH + px + 1];
-            const int sc = sp[0];
-            if (sc > 0) {
-                const int nb = max(max(imax3(sp[-SCORE_PITCH - 1], sp[-SCORE_PITCH], sp[-SCORE_PITCH + 1]),
-                                       imax3(sp[SCORE_PITCH - 1], sp[SCORE_PITCH], sp[SCORE_PITCH + 1])),
-                                   max((int)sp[-1], (int)sp[1]));
-                lm = sc > nb;
-                li = lm && sc >= iniTh;
+    const bool xin = lx < cw;
+    int total = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const int th = attempt == 0 ? iniTh : minTh;
+        int head = 0, tail = 0;  // wave-uniform ring positions, tail - head <= 127
+        int nCorn = 0;           // corners found (t* >= th); the first CORN_CAP are listed
+        // scores 64 queued candidates (lanes below `count`), marks corners in the score tile and the list
+        auto score_chunk = [&](int count) {
+            wave_lds_sync();
+            bool corner = false;
+            unsigned q = 0;
+            if (lane < count) {
+                q = cand[(head + lane) & 127];
+                const int qx = q & 255, qy = q >> 8;
+                const int t = fast_score(&tile[(qy + 3) * TILE_PITCH + qx + 3]);
+                corner = t >= th;
+                if (corner) score[(qy + 1) * SCORE_PITCH + qx + 1] = (uint8_t)t;
+            }
+            const unsigned long long m = __ballot(corner);
+            if (corner) {
+                const int pos = nCorn + __popcll(m & below);
+                if (pos < CORN_CAP) corn[pos] = (uint16_t)q;
+            }
+            nCorn += __popcll(m);
+            head += count;
+        };
+        {
+            const uint8_t* c = &tile[(ly + 3) * TILE_PITCH + lx + 3];
+            int y = ly;
+            for (int p = 0; p < steps; p++, y += rowsPerStep, c += rowsPerStep * TILE_PITCH) {
+                // (lanes outside the cell read tile bytes that belong to no pixel of it; their result is masked)
+                const int v = c[0];
+                const int dS = v - c[3 * TILE_PITCH], dE = v - c[3], dN = v - c[-3 * TILE_PITCH], dW = v - c[-3];
+                const int hiV = min(max(dS, dN), max(dE, dW));  // > th: an adjacent compass pair is darker
+                const int loV = max(min(dS, dN), min(dE, dW));  // < -th: an adjacent compass pair is brighter
+                const bool pass = xin & (y < ch) & ((hiV > th) | (loV < -th));
+                const unsigned long long m = __ballot(pass);
+                if (pass) cand[(tail + __popcll(m & below)) & 127] = (uint16_t)(lx | (y << 8));
+                tail += __popcll(m);
+                if (tail - head >= 64) score_chunk(64);
             }
         }
-        keepMin |= (unsigned long long)lm << p;
-        keepIni |= (unsigned long long)li << p;
-        cntMin += __popcll(__ballot(lm));
-        cntIni += __popcll(__ballot(li));
-    }
-    const unsigned long long keep = cntIni > 0 ? keepIni : keepMin;  // fallback decided after suppression, :852
-    const int total = cntIni > 0 ? cntIni : cntMin;
-    int run = 0;
-    for (int p = 0; p < rounds; p++) {
-        const bool f = (keep >> p) & 1ull;
-        const unsigned long long b = __ballot(f);
-        if (f) {
+        if (tail > head) score_chunk(tail - head);
+        wave_lds_sync();
+
+        unsigned long long keep = 0ull;
+        const bool listed = nCorn <= CORN_CAP;
+        const int rounds = listed ? (nCorn + 63) >> 6 : steps;
+        for (int p = 0; p < rounds; p++) {
+            bool lm = false;
             int px = lx, py = p * rowsPerStep + ly;
+            bool in = xin && py < ch;
             if (listed) {
-                const unsigned q = corn[p * 64 + lane];
+                in = p * 64 + lane < nCorn;
+                const unsigned q = in ? corn[p * 64 + lane] : 0u;
                 px = q & 255;
                 py = q >> 8;
             }
-            const int pos = run + __popcll(b & below);
-            const int sc = score[(py + 1) * SCORE_PITCH + px + 1];
-            if (pos < cellCap) out[pos] = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)sc << 16);
+            if (in) {
+                const uint8_t* sp = &score[(py + 1) * SCORE_PITCH + px + 1];
+                const int sc = sp[0];
+                if (sc >= th) {  // (a second attempt also sees the first one's scores: same values, all >= iniTh)
+                    const int nb = max(max(imax3(sp[-SCORE_PITCH - 1], sp[-SCORE_PITCH], sp[-SCORE_PITCH + 1]),
+                                           imax3(sp[SCORE_PITCH - 1], sp[SCORE_PITCH], sp[SCORE_PITCH + 1])),
+                                       max((int)sp[-1], (int)sp[1]));
+                    lm = sc > nb;
+                }
+            }
+            keep |= (unsigned long long)lm << p;
+            total += __popcll(__ballot(lm));
         }
-        run += __popcll(b);
+        if (total == 0 && attempt == 0 && minTh < iniTh) continue;  // nothing kept: lower threshold, :852-858
+        int run = 0;
+        for (int p = 0; p < rounds; p++) {
+            const bool f = (keep >> p) & 1ull;
+            const unsigned long long b = __ballot(f);
+            if (f) {
+                int px = lx, py = p * rowsPerStep + ly;
+                if (listed) {
+                    const unsigned q = corn[p * 64 + lane];
+                    px = q & 255;
+                    py = q >> 8;
+                }
+                const int pos = run + __popcll(b & below);
+                const int sc = score[(py + 1) * SCORE_PITCH + px + 1];
+                if (pos < cellCap) out[pos] = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)sc << 16);
+            }
+            run += __popcll(b);
+        }
+        break;
     }
     if (lane == 0) cellCount[cellGlobal] = total;  // total <= cellCap by the 2x2-block bound on strict local maxima
 }
