@@ -78,17 +78,27 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
     __syncthreads();
     // horizontal pass: column dx of every staged row (wave q takes rows q, q + 4, ...)
     if (colValid) {
-        for (int r = q; r < nrows; r += 4) {
-            const uint8_t* rowp = tile + r * tp - sxa;  // rowp[sx] is source pixel (sx, sy0 + r)
-            if (AREA) {
+        if (AREA) {
+            // The taps of a column are consecutive source pixels starting at si[0]: fetch the two aligned dwords
+            // that hold them, shift the first tap to byte 0, and always take four (unused taps have weight 0,
+            // and buf + pixel * 0 == buf exactly; what lies under them is some byte of the LDS allocation).
+            const int b0 = txa.si[0] - sxa;
+            const int sh = b0 & 3;
+            const uint32_t* rowp = (const uint32_t*)tile + (b0 >> 2);
+            const int rowStep = tp >> 2;
+            for (int r = q; r < nrows; r += 4) {
+                const uint32_t lo = rowp[r * rowStep], hi = rowp[r * rowStep + 1];
+                const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
                 float buf = 0.f;
-#pragma unroll
-                for (int k = 0; k < ORB_MAX_TAPS; k++) {
-                    if (txa.a[k] == 0.f) break;
-                    buf = __fadd_rn(buf, __fmul_rn((float)rowp[txa.si[k]], txa.a[k]));
-                }
+                buf = __fadd_rn(buf, __fmul_rn((float)(w & 255u), txa.a[0]));
+                buf = __fadd_rn(buf, __fmul_rn((float)((w >> 8) & 255u), txa.a[1]));
+                buf = __fadd_rn(buf, __fmul_rn((float)((w >> 16) & 255u), txa.a[2]));
+                buf = __fadd_rn(buf, __fmul_rn((float)(w >> 24), txa.a[3]));
                 bufF[r * ORB_RS_TW + dx] = buf;
-            } else {
+            }
+        } else {
+            for (int r = q; r < nrows; r += 4) {
+                const uint8_t* rowp = tile + r * tp - sxa;  // rowp[sx] is source pixel (sx, sy0 + r)
                 bufI[r * ORB_RS_TW + dx] = rowp[txl.s0] * txl.a0 + rowp[txl.s1] * txl.a1;
             }
         }
