@@ -343,15 +343,20 @@ QT_FN void qt_distribute(const QtWork& w, int n, int nIni, int N, int n3quirk, Q
         // ---- fine phase, src/ORBextractor.cc:702-770 ------------------------------
         while (sh->fine && !sh->finish) {
             const int nLf = sh->nL, nR = sh->nRec;
-            // order recorded nodes by (size, creation number) descending
+            // order recorded nodes by (size, creation number) descending: sizes and creation numbers are
+            // first laid out densely, so that the counting loop reads two words per step and nothing else
             for (int j = t; j < nR; j += T) {
                 const OrbNode a = cur[w.rec[j]];
-                const int sa = a.hi - a.lo;
+                w.scanA[j] = a.hi - a.lo;
+                w.scanB[j] = a.seq;
+            }
+            QT_BARRIER();
+            for (int j = t; j < nR; j += T) {
+                const int sa = w.scanA[j], qa = w.scanB[j];
                 int r = 0;
                 for (int m = 0; m < nR; m++) {
-                    const OrbNode c = cur[w.rec[m]];
-                    const int sc = c.hi - c.lo;
-                    r += (sc > sa) || (sc == sa && c.seq > a.seq);
+                    const int sc = w.scanA[m], qc = w.scanB[m];
+                    r += (sc > sa) || (sc == sa && qc > qa);
                 }
                 w.recSorted[r] = w.rec[j];
             }
