@@ -24,10 +24,16 @@
 #include "orb_internal.h"
 
 #define FAST_WAVES 4
-#define TILE_PITCH 72                                   // >= 59 + 6, multiple of 4
-#define TILE_ROWS 66                                    // >= 59 + 6
-#define SCORE_PITCH 64                                  // >= 59 + 2
-#define SCORE_ROWS 62                                   // >= 59 + 2
+// LDS geometry per wavefront, a template parameter of the kernel: the pixel tile holds the cell interior
+// plus a 3-pixel halo (plus up to 3 bytes of alignment slack per row and one spare row that the
+// two-rows-per-step walk may touch), the score tile the interior plus a zero rim.  Two instances: cells up
+// to 37 x 35 (every level of the usual frame sizes) and the general one up to 59 x 59.
+struct TileSmall {
+    static constexpr int TILE_PITCH = 48, TILE_ROWS = 42, SCORE_PITCH = 40, SCORE_ROWS = 37, MAX_W = 37, MAX_H = 35;
+};
+struct TileLarge {
+    static constexpr int TILE_PITCH = 72, TILE_ROWS = 66, SCORE_PITCH = 64, SCORE_ROWS = 62, MAX_W = 59, MAX_H = 59;
+};
 #define CORN_CAP 256                                    // corners listed per cell for the suppression pass
 
 static __device__ __forceinline__ void wave_lds_sync() {
@@ -54,6 +60,7 @@ static __device__ __forceinline__ int imax3(int a, int b, int c) {
 
 // t* = max(A, B) - 1 with A = max over the 16 arcs of 9 contiguous ring pixels
 // of min(v - ring), B likewise for (ring - v)   (cv::cornerScore<16>).
+template <int TILE_PITCH>
 static __device__ __forceinline__ int fast_score(const uint8_t* c) {
     // c points at the centre inside the LDS tile
     const int v = c[0];
@@ -94,12 +101,14 @@ static __device__ __forceinline__ int fast_score(const uint8_t* c) {
     return max(A, -Bn) - 1;
 }
 
+template <class TG>
 __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(const OrbGeom* __restrict__ g,
                                                                const uint8_t* __restrict__ img0, int stride0,
                                                                int64_t frameStride0, const uint8_t* __restrict__ pyr,
                                                                int frame0, int nframes,
                                                                uint32_t* __restrict__ cellKeys,
                                                                int* __restrict__ cellCount) {
+    constexpr int TILE_PITCH = TG::TILE_PITCH, TILE_ROWS = TG::TILE_ROWS, SCORE_PITCH = TG::SCORE_PITCH, SCORE_ROWS = TG::SCORE_ROWS;
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[FAST_WAVES][TILE_ROWS * TILE_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t s_score[FAST_WAVES][SCORE_ROWS * SCORE_PITCH];
     __shared__ uint16_t s_cand[FAST_WAVES][128];
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(const OrbGeom* _
             if (lane < count) {
                 q = cand[(head + lane) & 127];
                 const int qx = q & 255, qy = q >> 8;
-                const int t = fast_score(&tile[(qy + 3) * TILE_PITCH + qx + 3]);
+                const int t = fast_score<TILE_PITCH>(&tile[(qy + 3) * TILE_PITCH + qx + 3]);
                 corner = t >= th;
                 if (corner) score[(qy + 1) * SCORE_PITCH + qx + 1] = (uint8_t)t;
             }
@@ -294,8 +303,15 @@ int orb_launch_fast(const OrbBatch& b) {
     const OrbGeom& g = *b.h_geom;
     const int64_t cells = (int64_t)b.nframes * g.cellsPerFrame;
     const int64_t blocks = (cells + FAST_WAVES - 1) / FAST_WAVES;
-    hipLaunchKernelGGL(k_fast_cells, dim3((unsigned)blocks), dim3(64 * FAST_WAVES), 0, (hipStream_t)b.stream, b.d_geom,
-                       b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, b.nframes, b.d_cellKeys, b.d_cellCount);
+    // (orb_api.hip refuses geometries whose cells exceed 59 x 59 before anything is launched)
+    if (g.maxCellW <= TileSmall::MAX_W && g.maxCellH <= TileSmall::MAX_H)
+        hipLaunchKernelGGL(k_fast_cells<TileSmall>, dim3((unsigned)blocks), dim3(64 * FAST_WAVES), 0, (hipStream_t)b.stream,
+                           b.d_geom, b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, b.nframes, b.d_cellKeys,
+                           b.d_cellCount);
+    else
+        hipLaunchKernelGGL(k_fast_cells<TileLarge>, dim3((unsigned)blocks), dim3(64 * FAST_WAVES), 0, (hipStream_t)b.stream,
+                           b.d_geom, b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, b.nframes, b.d_cellKeys,
+                           b.d_cellCount);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         orb_set_error("fast launch failed: %s", hipGetErrorString(e));

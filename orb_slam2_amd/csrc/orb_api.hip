@@ -359,6 +359,8 @@ static int compute_geom(orb_ctx* c, int w, int h) {
                 const int cw = maxX - 3 - (iniX + 3);
                 if (cw <= 0) continue;
                 const int cap = halfUp(cw) * halfUp(ch);
+                g.maxCellW = std::max(g.maxCellW, cw);
+                g.maxCellH = std::max(g.maxCellH, ch);
                 keys += cap;
                 cellCap = std::max(cellCap, cap);
             }

@@ -39,6 +39,7 @@ struct OrbLevel {
 struct OrbGeom {
     int nlevels, w, h;
     int cellsPerFrame, cellCap;   // cellCap: key slots per cell
+    int maxCellW, maxCellH;       // largest FAST cell interior over all levels
     int outCapFrame;              // sum of outCap
     int64_t keysPerFrame;         // sum of keyCap
     int64_t nodesPerFrame;        // sum of nodeCap
