@@ -148,7 +148,6 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
                                                              int* __restrict__ error) {
     __shared__ __attribute__((aligned(16))) uint8_t s_raw[DESC_WAVES][RAW_N * RAW_P];
     __shared__ __attribute__((aligned(16))) uint16_t s_hb[DESC_WAVES][RAW_N * HB_P];
-    __shared__ __attribute__((aligned(16))) uint8_t s_bl[DESC_WAVES][BL_N * BL_P];
     // the wavefront index is the same in all 64 lanes: telling the compiler so keeps everything derived from
     // it (frame, level, keypoint, window addresses, loop bounds) in scalar registers
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -192,7 +191,8 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     }
     uint8_t* raw = s_raw[wave];
     uint16_t* hb = s_hb[wave];
-    uint8_t* bl = s_bl[wave];
+    uint8_t* bl = s_raw[wave];  // the blurred window (37 x 44 bytes) takes the place of the source window, which the
+                                // horizontal pass has consumed by the time the vertical pass writes it
 
     // 43x43 source window.  Interior keypoints on 4-byte-aligned rows take whole dwords (12 per row,
     // the window then starts `off` bytes into the LDS row); keypoints whose window leaves the level

@@ -29,10 +29,10 @@
 // two-rows-per-step walk may touch), the score tile the interior plus a zero rim.  Two instances: cells up
 // to 37 x 35 (every level of the usual frame sizes) and the general one up to 59 x 59.
 struct TileSmall {
-    static constexpr int TILE_PITCH = 48, TILE_ROWS = 42, SCORE_PITCH = 40, SCORE_ROWS = 37, MAX_W = 37, MAX_H = 35;
+    static constexpr int TILE_PITCH = 48, TILE_ROWS = 42, SCORE_PITCH = 40, SCORE_ROWS = 37, MAX_W = 37, MAX_H = 35, WAVES_PER_SIMD = 8;
 };
 struct TileLarge {
-    static constexpr int TILE_PITCH = 72, TILE_ROWS = 66, SCORE_PITCH = 64, SCORE_ROWS = 62, MAX_W = 59, MAX_H = 59;
+    static constexpr int TILE_PITCH = 72, TILE_ROWS = 66, SCORE_PITCH = 64, SCORE_ROWS = 62, MAX_W = 59, MAX_H = 59, WAVES_PER_SIMD = 4;
 };
 #define CORN_CAP 256                                    // corners listed per cell for the suppression pass
 
@@ -101,8 +101,11 @@ static __device__ __forceinline__ int fast_score(const uint8_t* c) {
     return max(A, -Bn) - 1;
 }
 
+// The kernel waits on LDS round trips far more than it computes: the register budget is set so that the
+// wavefronts the LDS footprint admits are also resident (8 per SIMD for the small instance).
 template <class TG>
-__global__ __launch_bounds__(64 * FAST_WAVES) void k_fast_cells(const OrbGeom* __restrict__ g,
+__global__ __launch_bounds__(64 * FAST_WAVES)
+__attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) void k_fast_cells(const OrbGeom* __restrict__ g,
                                                                const uint8_t* __restrict__ img0, int stride0,
                                                                int64_t frameStride0, const uint8_t* __restrict__ pyr,
                                                                int frame0, int nframes,
