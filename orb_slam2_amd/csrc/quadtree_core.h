@@ -551,19 +551,35 @@ QT_FN void qt_select_all(const unsigned long long* sorted, const OrbNode* list, 
     }
     QT_BARRIER();
     const int nBig = sh->nBig < QT_BIG_LIST ? sh->nBig : QT_BIG_LIST;
+#ifdef ORB_HOST_EMU
     for (int k = 0; k < nBig; k++) {
         const int i = sh->bigList[k];
         const OrbNode nd = list[i];
-        if (t == 0) sh->best32 = 0u;
-        QT_BARRIER();
         uint32_t best = 0u;
-        for (int p = nd.lo + t; p < nd.hi; p += T) {
+        for (int p = nd.lo; p < nd.hi; p++) {
             const uint32_t pr = qt_entry_prio(sorted[p]);
             if (pr > best) best = pr;
         }
-        if (best) QT_ATOMIC_MAX32(&sh->best32, best);
-        QT_BARRIER();
-        if (t == 0) outRank[i] = (int)(~sh->best32 & 0xffffffu);
-        QT_BARRIER();
+        outRank[i] = (int)(~best & 0xffffffu);
     }
+#else
+    // one wavefront per large node, the wavefronts of the workgroup working on different nodes at once
+    const int lane = t & 63, wv = t >> 6, nw = (T + 63) >> 6;
+    for (int k = wv; k < nBig; k += nw) {
+        const int i = sh->bigList[k];
+        const OrbNode nd = list[i];
+        uint32_t best = 0u;
+        for (int p = nd.lo + lane; p < nd.hi; p += 64) {
+            const uint32_t pr = qt_entry_prio(sorted[p]);
+            if (pr > best) best = pr;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t v = (uint32_t)__shfl_xor((int)best, o, 64);
+            if (v > best) best = v;
+        }
+        if (lane == 0) outRank[i] = (int)(~best & 0xffffffu);
+    }
+    QT_BARRIER();
+#endif
 }
