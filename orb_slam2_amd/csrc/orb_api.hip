@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "orb_internal.h"
@@ -91,6 +92,8 @@ struct PinBuf {  // page-locked host staging: one DMA per direction instead of p
 };
 
 #define ORB_MAX_PARTS 4
+#define ORB_STAGE_THREADS 4      // host threads that stage a batch of host frames
+#define ORB_STAGE_SLICE 4        // frames per host-to-device copy
 #define ORB_MIN_PART_FRAMES 8   // groups smaller than this do not fill the device; the batch is then not split
 
 struct orb_ctx {
@@ -772,21 +775,41 @@ extern "C" int orb_extract_batch(orb_ctx* c, const uint8_t* const* imgs, int n, 
     const int cap = orb_max_keypoints_per_frame(c);
     const int dstride = c->inputStride;
     const int64_t fstride = (int64_t)dstride * h;
-    // frames -> page-locked staging in the device layout (row copies on the host), then one DMA
+    // frames -> page-locked staging in the device layout (row copies on the host) -> device.  A single
+    // host thread copies at a fraction of the link rate, so a batch is staged by up to four threads, each
+    // handing its frames to the DMA engine in slices as it goes (host copies and DMA overlap).
     if ((rc = c->pinIn.ensure((size_t)n * fstride))) return rc;
-    for (int f = 0; f < n; f++) {
+    for (int f = 0; f < n; f++)
         if (!imgs[f]) {
             orb_set_error("frame %d is null", f);
             return ORB_ERR_INVALID;
         }
-        uint8_t* dst = (uint8_t*)c->pinIn.p + f * fstride;
-        if (stride == dstride) {
-            memcpy(dst, imgs[f], (size_t)stride * (h - 1) + w);
-        } else {
-            for (int r = 0; r < h; r++) memcpy(dst + (size_t)r * dstride, imgs[f] + (size_t)r * stride, (size_t)w);
-        }
+    {
+        const int nthreads = std::max(1, std::min(ORB_STAGE_THREADS, n / ORB_STAGE_SLICE));
+        hipError_t terr[ORB_STAGE_THREADS];
+        auto stage = [&](int t) {
+            terr[t] = t ? hipSetDevice(c->prm.device) : hipSuccess;
+            const int f0 = (int)((int64_t)n * t / nthreads), f1 = (int)((int64_t)n * (t + 1) / nthreads);
+            for (int s0 = f0; s0 < f1 && terr[t] == hipSuccess; s0 += ORB_STAGE_SLICE) {
+                const int s1 = std::min(f1, s0 + ORB_STAGE_SLICE);
+                for (int f = s0; f < s1; f++) {
+                    uint8_t* dst = (uint8_t*)c->pinIn.p + f * fstride;
+                    if (stride == dstride) {
+                        memcpy(dst, imgs[f], (size_t)stride * (h - 1) + w);
+                    } else {
+                        for (int r = 0; r < h; r++) memcpy(dst + (size_t)r * dstride, imgs[f] + (size_t)r * stride, (size_t)w);
+                    }
+                }
+                terr[t] = hipMemcpyAsync((uint8_t*)c->dInput.p + s0 * fstride, (uint8_t*)c->pinIn.p + s0 * fstride,
+                                         (size_t)(s1 - s0) * fstride, hipMemcpyHostToDevice, c->stream);
+            }
+        };
+        std::thread workers[ORB_STAGE_THREADS];
+        for (int t = 1; t < nthreads; t++) workers[t] = std::thread(stage, t);
+        stage(0);
+        for (int t = 1; t < nthreads; t++) workers[t].join();
+        for (int t = 0; t < nthreads; t++) HIP_TRY(terr[t]);
     }
-    HIP_TRY(hipMemcpyAsync(c->dInput.p, c->pinIn.p, (size_t)n * fstride, hipMemcpyHostToDevice, c->stream));
     rc = run_batch(c, (const uint8_t*)c->dInput.p, n, w, h, dstride, fstride, (orb_keypoint*)c->dKps.p,
                    (uint8_t*)c->dDesc.p, cap, (int*)c->dNOut.p, c->stream);
     if (rc) return rc;

@@ -11,6 +11,9 @@ timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INST
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU --output-format csv -d $OUT -o p2 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu "$@" > $OUT/p2.log 2>&1 &&
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o p3 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu "$@" > $OUT/p3.log 2>&1 &&
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o p4 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 1 --no-cpu "$@" > $OUT/p4.log 2>&1 || exit 1
+# kernel trace, single group: the per-kernel averages are whole-batch launches, as in bench.py's stage timing
+timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o kt1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu "$@" > $OUT/kt1.log 2>&1 || exit 1
 unset ORBHIP_PARTS
+# kernel trace of the default run (three frame groups on three streams; launches of mixed size)
 timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o kt -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu "$@" > $OUT/kt.log 2>&1
 ls $OUT
