@@ -7,22 +7,35 @@
 //
 // Levels of everyday frame sizes keep the sorted keys and all node scratch in
 // LDS; larger ones (a 4K level holds ~1e5 keys) use the global-memory buffers
-// of the same layout.
+// of the same layout.  The kernel is bound by latency, not by issue rate, so
+// its speed is proportional to the workgroups a CU can hold: the LDS block is
+// sized per launch (QtLaunch) to what the levels of that launch need.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 
 #include "quadtree_core.h"
 
 #define QT_MAX_THREADS 1024
-#define QT_LDS_KEYS 4096
+#define QT_LDS_KEYS_MAX 4096
+#define QT_STATIC_LDS 1024     // bound on sizeof(QtShared)
+
+struct QtLaunch {
+    int level0, nlevels;  // levels [level0, level0 + nlevels) of every frame
+    int ldsKeys;          // sort entries the LDS block holds
+    int binBits;          // key-sort buckets = 2^binBits
+    int regionInts;       // ints behind the keys: bucket arrays, then node scratch
+};
 
 // Sort, distribute, select and emit one level.  Inlined once per memory placement so that the
 // compiler sees which address space `sorted` and the node scratch live in.
 static __device__ __forceinline__ int qt_level(const OrbGeom* g, const OrbLevel& L, const unsigned long long* tmp,
                                                unsigned long long* sorted, const QtWork& w0, int n,
                                                const uint32_t* __restrict__ levelCellKeys, uint32_t* __restrict__ selXY,
-                                               int* __restrict__ selScore, int* __restrict__ error, QtShared* sh) {
+                                               int* __restrict__ selScore, int* __restrict__ error, const QtBins bins,
+                                               QtShared* sh) {
     const int t = threadIdx.x, T = (int)blockDim.x;
-    qt_sort_keys(tmp, sorted, n, L.nIni, sh);
+    qt_sort_keys(tmp, sorted, n, L.nIni, bins, sh);
     __syncthreads();  // the bucket arrays may now be reused as node scratch
     QtWork w = w0;
     w.sorted = sorted;
@@ -49,7 +62,7 @@ static __device__ __forceinline__ int qt_level(const OrbGeom* g, const OrbLevel&
     return count;
 }
 
-__global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __restrict__ g, int frame0, int nframes,
+__global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __restrict__ g, const QtLaunch q, int frame0, int nframes,
                                                         const uint32_t* __restrict__ cellKeys,
                                                         const int* __restrict__ cellCount,
                                                         unsigned long long* __restrict__ sortBuf,
@@ -57,11 +70,15 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __re
                                                         uint32_t* __restrict__ selXY, int* __restrict__ selScore,
                                                         int* __restrict__ levelCount, int* __restrict__ levelKeys,
                                                         int* __restrict__ error) {
+    static_assert(sizeof(QtShared) <= QT_STATIC_LDS, "QtShared outgrew its bound");
     __shared__ QtShared sh;
-    __shared__ unsigned long long s_keys[QT_LDS_KEYS];
+    extern __shared__ unsigned long long s_dyn[];  // q.ldsKeys entries, then q.regionInts ints
+    unsigned long long* const s_keys = s_dyn;
+    int* const s_region = (int*)(s_dyn + q.ldsKeys);
+    const QtBins bins = {s_region, s_region + (1 << q.binBits) + 1, q.binBits};
     const int nlevels = g->nlevels;
     // level-major launch order: the levels with the most keys (the longest-running workgroups) start first
-    const int level = blockIdx.x / nframes, frame = frame0 + blockIdx.x % nframes;
+    const int level = q.level0 + blockIdx.x / nframes, frame = frame0 + blockIdx.x % nframes;
     const OrbLevel& L = g->lv[level];
     const int t = threadIdx.x, T = (int)blockDim.x;
     unsigned long long* sortedG = sortBuf + ((int64_t)frame * g->keysPerFrame + L.keyBase) * 2;
@@ -75,9 +92,10 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __re
     const int nCells = L.nCols * L.nRows, cellCap = g->cellCap;
     const int height = L.maxBorderY - ORB_BORDER;
     int n = 0;
-    for (int c0 = 0; c0 < nCells; c0 += QT_BINS) {
-        const int m = nCells - c0 < QT_BINS ? nCells - c0 : QT_BINS;
-        int* off = sh.binStart;
+    const int chunkCells = 1 << q.binBits;
+    for (int c0 = 0; c0 < nCells; c0 += chunkCells) {
+        const int m = nCells - c0 < chunkCells ? nCells - c0 : chunkCells;
+        int* off = bins.start;
         for (int c = t; c < m; c += T) off[c] = cc[c0 + c];
         __syncthreads();
         qt_scan(off, m, &sh);
@@ -111,9 +129,9 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __re
     if (n > 0) {
         const int64_t ob = (int64_t)frame * g->outCapFrame + L.outBase;
         QtWork w;
-        if (n <= QT_LDS_KEYS && QT_NODE_INTS(L.nodeCap) <= QT_POOL_INTS) {
-            qt_work_from_pool(&w, sh.binStart, L.nodeCap);
-            count = qt_level(g, L, tmp, s_keys, w, n, lck, selXY + ob, selScore + ob, error, &sh);
+        if (n <= q.ldsKeys && QT_NODE_INTS(L.nodeCap) <= q.regionInts) {
+            qt_work_from_pool(&w, s_region, L.nodeCap);
+            count = qt_level(g, L, tmp, s_keys, w, n, lck, selXY + ob, selScore + ob, error, bins, &sh);
         } else {
             OrbNode* nb = nodes + ((int64_t)frame * g->nodesPerFrame + L.nodeBase) * 2;
             int* p = ints + ((int64_t)frame * g->nodesPerFrame + L.nodeBase) * 9 + (int64_t)(frame * nlevels + level) * 4;
@@ -131,17 +149,48 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __re
             w.scanB = p;
             p += L.nodeCap + 1;
             w.scanC = p;
-            count = qt_level(g, L, tmp, sortedG, w, n, lck, selXY + ob, selScore + ob, error, &sh);
+            count = qt_level(g, L, tmp, sortedG, w, n, lck, selXY + ob, selScore + ob, error, bins, &sh);
         }
     }
     if (t == 0) levelCount[frame * nlevels + level] = count;
+}
+
+// LDS block for levels [level0, level0 + nlevels): the bucket arrays and the largest node pool of these
+// levels share the region behind the keys; levels whose node pool would push the block past 64 KB
+// (quotas in the thousands) run from global memory anyway.
+static QtLaunch qt_plan(const OrbGeom& g, int level0, int nlevels, int ldsKeys) {
+    QtLaunch q;
+    q.level0 = level0;
+    q.nlevels = nlevels;
+    q.ldsKeys = ldsKeys;
+    int pool = 0;
+    for (int l = level0; l < level0 + nlevels; l++) pool = std::max(pool, QT_NODE_INTS(g.lv[l].nodeCap));
+    // about two keys per bucket when the block is full; more buckets when the node pool leaves the room
+    for (int attempt = 0; attempt < 2; attempt++) {
+        int bits = 8;
+        while ((2 << bits) < ldsKeys && bits < QT_MAX_BIN_BITS) bits++;
+        while (bits < QT_MAX_BIN_BITS && QT_BIN_INTS(bits + 1) <= pool) bits++;
+        q.binBits = bits;
+        q.regionInts = std::max(pool, QT_BIN_INTS(bits));
+        if ((size_t)ldsKeys * 8 + (size_t)q.regionInts * 4 + QT_STATIC_LDS <= 65536) break;
+        // such levels use the global buffers: no keys in LDS, and all the buckets the sort can use
+        pool = 0;
+        ldsKeys = 0;
+        q.ldsKeys = 0;
+        q.binBits = QT_MAX_BIN_BITS;
+        q.regionInts = QT_BIN_INTS(QT_MAX_BIN_BITS);
+        break;
+    }
+    return q;
 }
 
 int orb_launch_quadtree(const OrbBatch& b) {
     const OrbGeom& g = *b.h_geom;
     // large levels (4K frames hand ~1e5 keys to the quadtree) get a full 1024-thread workgroup
     const int threads = g.lv[0].keyCap > 400000 ? 1024 : 256;
-    hipLaunchKernelGGL(k_quadtree, dim3(b.nframes * g.nlevels), dim3(threads), 0, (hipStream_t)b.stream, b.d_geom,
+    const QtLaunch q = qt_plan(g, 0, g.nlevels, QT_LDS_KEYS_MAX);
+    const size_t lds = (size_t)q.ldsKeys * 8 + (size_t)q.regionInts * 4;
+    hipLaunchKernelGGL(k_quadtree, dim3(b.nframes * q.nlevels), dim3(threads), lds, (hipStream_t)b.stream, b.d_geom, q,
                        b.frame0, b.nframes, b.d_cellKeys, b.d_cellCount, b.d_sort, b.d_nodes, b.d_ints, b.d_selXY, b.d_selScore, b.d_levelCount,
                        b.d_levelKeys, b.d_error);
     hipError_t e = hipGetLastError();

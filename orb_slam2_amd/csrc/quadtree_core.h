@@ -47,11 +47,11 @@ static inline int qt_host_fetch_add(int* p, int v) {
 #define QT_NOMORE 0x100
 #define QT_DEPTH(n) ((n).depthFlags & 0xff)
 
-#define QT_BINS 4096      // buckets of the key sort
+#define QT_MAX_BIN_BITS 12  // the key sort uses 2^bits buckets, bits chosen per launch (QtBins)
 #define QT_SMALL_BIN 40   // buckets up to this size are sorted by one thread
 
 #define QT_BIG_LIST 128   // nodes handed to the whole workgroup by the winner selection
-#define QT_POOL_INTS (2 * QT_BINS + 1)
+#define QT_BIN_INTS(bits) ((2 << (bits)) + 1)  // ints of bucket scratch: 2^bits + 1 starts, 2^bits cursors
 #define QT_NODE_INTS(cap) (17 * (cap) + 3)  // ints of node scratch one (frame, level) needs, see qt_work_from_pool
 
 // Sort entry: quadtree path << 32 | rank << 8 | response.  The rank (24 bits) numbers the level's keys
@@ -69,15 +69,19 @@ QT_FN uint32_t qt_entry_prio(unsigned long long e) {
 
 struct QtShared {
     int part[64];    // per-wavefront partial sums of the block scan
-    // Key-sort buckets; once the keys are sorted the same words serve as node scratch (QT_POOL_INTS ints
-    // from binStart on) when a level's node pool fits.
-    int binStart[QT_BINS + 1];
-    int binCursor[QT_BINS];
     int bigList[QT_BIG_LIST];
     int nBig;
     unsigned best32;
     int total;
     int nL, prevSize, nToExpand, seqCounter, nRec, finish, fine, stop, err;
+};
+
+// Key-sort buckets.  Once the keys are sorted the same words serve as node scratch when a level's
+// node pool fits (QT_NODE_INTS ints from `start` on).
+struct QtBins {
+    int* start;   // 2^bits + 1
+    int* cursor;  // 2^bits
+    int bits;
 };
 
 struct QtWork {  // scratch of one (frame, level): LDS when it fits, global memory otherwise
@@ -478,33 +482,36 @@ QT_FN int qt_select(const unsigned long long* sorted, const OrbNode& nd) {
 // every bucket into its final slice; buckets are then ordered internally, small
 // ones by one thread each, large ones by the whole workgroup.  Entries are
 // unique, so the result does not depend on the order atomics were served in.
-QT_FN void qt_sort_keys(const unsigned long long* tmp, unsigned long long* sorted, int n, int nIni, QtShared* sh) {
+QT_FN void qt_sort_keys(const unsigned long long* tmp, unsigned long long* sorted, int n, int nIni, const QtBins bins,
+                        QtShared* sh) {
     const int T = QT_NT, t = QT_TID;
     const uint32_t maxCode = ((uint32_t)nIni << (2 * ORB_CODE_DEPTH)) - 1u;  // nIni <= 16
     int bits = 0;
     while ((maxCode >> bits) != 0u && bits < 32) bits++;
-    const int shift = bits > 12 ? bits - 12 : 0;
-    const int nb = (int)(maxCode >> shift) + 1;  // <= QT_BINS
-    for (int b = t; b <= nb; b += T) sh->binStart[b] = 0;
+    const int shift = bits > bins.bits ? bits - bins.bits : 0;
+    const int nb = (int)(maxCode >> shift) + 1;  // <= 2^bins.bits
+    int* const binStart = bins.start;
+    int* const binCursor = bins.cursor;
+    for (int b = t; b <= nb; b += T) binStart[b] = 0;
     if (t == 0) sh->nBig = 0;
     QT_BARRIER();
-    for (int r = t; r < n; r += T) QT_ATOMIC_ADD(&sh->binStart[(uint32_t)(tmp[r] >> 32) >> shift], 1);
+    for (int r = t; r < n; r += T) QT_ATOMIC_ADD(&binStart[(uint32_t)(tmp[r] >> 32) >> shift], 1);
     QT_BARRIER();
-    qt_scan(sh->binStart, nb, sh);
-    for (int b = t; b < nb; b += T) sh->binCursor[b] = sh->binStart[b];
+    qt_scan(binStart, nb, sh);
+    for (int b = t; b < nb; b += T) binCursor[b] = binStart[b];
     QT_BARRIER();
     for (int r = t; r < n; r += T) {
         const unsigned long long e = tmp[r];
-        const int pos = QT_ATOMIC_ADD(&sh->binCursor[(uint32_t)(e >> 32) >> shift], 1);
+        const int pos = QT_ATOMIC_ADD(&binCursor[(uint32_t)(e >> 32) >> shift], 1);
         sorted[pos] = e;
     }
     QT_BARRIER();
     // binCursor is free again: it now collects the buckets that need the workgroup
     for (int b = t; b < nb; b += T) {
-        const int lo = sh->binStart[b], m = sh->binStart[b + 1] - lo;
+        const int lo = binStart[b], m = binStart[b + 1] - lo;
         if (m <= 1) continue;
         if (m > QT_SMALL_BIN) {
-            sh->binCursor[QT_ATOMIC_ADD(&sh->nBig, 1)] = b;
+            binCursor[QT_ATOMIC_ADD(&sh->nBig, 1)] = b;
             continue;
         }
         unsigned long long* a = sorted + lo;
@@ -521,9 +528,9 @@ QT_FN void qt_sort_keys(const unsigned long long* tmp, unsigned long long* sorte
     QT_BARRIER();
     const int nBig = sh->nBig;
     for (int k = 0; k < nBig; k++) {
-        const int b = sh->binCursor[k];
-        const int lo = sh->binStart[b];
-        qt_sort(sorted + lo, sh->binStart[b + 1] - lo);
+        const int b = binCursor[k];
+        const int lo = binStart[b];
+        qt_sort(sorted + lo, binStart[b + 1] - lo);
     }
 }
 

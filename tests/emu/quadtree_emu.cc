@@ -7,6 +7,9 @@
 
 #include "../../orb_slam2_amd/csrc/quadtree_core.h"
 
+static int g_binBits = QT_MAX_BIN_BITS;
+extern "C" void qt_emu_set_bin_bits(int bits) { g_binBits = bits; }  // 1..QT_MAX_BIN_BITS, as a launch would choose
+
 extern "C" int qt_emu_distribute(const int* xs, const int* ys, const int* scores, int n, int nIni, float hX, int height,
                                  int N, int n3quirk, int* outRank, int outCap, int* err) {
     std::vector<unsigned long long> sorted(n > 0 ? n : 1), tmp(n > 0 ? n : 1);
@@ -14,7 +17,9 @@ extern "C" int qt_emu_distribute(const int* xs, const int* ys, const int* scores
     // ranks with gaps, as the device numbers them (cell * capacity + position)
     for (int i = 0; i < n; i++)
         tmp[i] = qt_entry(qt_code(xs[i], ys[i], nIni, hX, height), (uint32_t)(3 * i + 1), (uint32_t)scores[i]);
-    if (n > 0) qt_sort_keys(tmp.data(), sorted.data(), n, nIni, &sh);
+    std::vector<int> binInts((std::size_t)QT_BIN_INTS(g_binBits));
+    const QtBins bins = {binInts.data(), binInts.data() + (1 << g_binBits) + 1, g_binBits};
+    if (n > 0) qt_sort_keys(tmp.data(), sorted.data(), n, nIni, bins, &sh);
     for (int i = 1; i < n; i++)
         if (sorted[i - 1] > sorted[i]) return -100;
     const int nodeCap = (N + 3 > 4 * nIni ? N + 3 : 4 * nIni) + 8;

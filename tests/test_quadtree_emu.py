@@ -94,4 +94,6 @@ def test_emu_matches_oracle_on_random_keys(emu, oracle, quirk):
         keys = np.zeros(len(first), dtype=oracle.KP_DTYPE)
         keys["x"], keys["y"], keys["response"] = xs[first], ys[first], sc[first]
         keys["size"], keys["angle"], keys["class_id"] = 7, -1, -1
+        emu.qt_emu_set_bin_bits([12, 11, 10, 6, 1][trial % 5])  # bucket counts a launch may choose, and tiny ones
         check(emu, oracle, e, keys, 16, 16 + w, 16, 16 + h, N, quirk)
+    emu.qt_emu_set_bin_bits(12)
