@@ -117,7 +117,10 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __re
         n += chunk;
         __syncthreads();
     }
-    if (t == 0) levelKeys[frame * nlevels + level] = n;
+    if (t == 0) {
+        levelKeys[frame * nlevels + level] = n;
+        if (n > error[1]) atomicMax(&error[1], n);  // sizes the LDS block of later launches
+    }
     if (n > L.keyCap) {  // cannot happen: keyCap is the 2x2-block bound summed over the cells
         if (t == 0) {
             atomicOr(error, 4);
@@ -165,10 +168,10 @@ static QtLaunch qt_plan(const OrbGeom& g, int level0, int nlevels, int ldsKeys) 
     q.ldsKeys = ldsKeys;
     int pool = 0;
     for (int l = level0; l < level0 + nlevels; l++) pool = std::max(pool, QT_NODE_INTS(g.lv[l].nodeCap));
-    // about two keys per bucket when the block is full; more buckets when the node pool leaves the room
+    // about four keys per bucket when the block is full; more buckets when the node pool leaves the room
     for (int attempt = 0; attempt < 2; attempt++) {
         int bits = 8;
-        while ((2 << bits) < ldsKeys && bits < QT_MAX_BIN_BITS) bits++;
+        while ((4 << bits) < ldsKeys && bits < QT_MAX_BIN_BITS) bits++;
         while (bits < QT_MAX_BIN_BITS && QT_BIN_INTS(bits + 1) <= pool) bits++;
         q.binBits = bits;
         q.regionInts = std::max(pool, QT_BIN_INTS(bits));
@@ -188,7 +191,10 @@ int orb_launch_quadtree(const OrbBatch& b) {
     const OrbGeom& g = *b.h_geom;
     // large levels (4K frames hand ~1e5 keys to the quadtree) get a full 1024-thread workgroup
     const int threads = g.lv[0].keyCap > 400000 ? 1024 : 256;
-    const QtLaunch q = qt_plan(g, 0, g.nlevels, QT_LDS_KEYS_MAX);
+    // keys in LDS: the largest level met so far plus an eighth; the full block until a count has arrived
+    int ldsKeys = QT_LDS_KEYS_MAX;
+    if (b.qtKeysSeen > 0) ldsKeys = std::min(QT_LDS_KEYS_MAX, std::max(512, (b.qtKeysSeen + b.qtKeysSeen / 8 + 63) & ~63));
+    const QtLaunch q = qt_plan(g, 0, g.nlevels, ldsKeys);
     const size_t lds = (size_t)q.ldsKeys * 8 + (size_t)q.regionInts * 4;
     hipLaunchKernelGGL(k_quadtree, dim3(b.nframes * q.nlevels), dim3(threads), lds, (hipStream_t)b.stream, b.d_geom, q,
                        b.frame0, b.nframes, b.d_cellKeys, b.d_cellCount, b.d_sort, b.d_nodes, b.d_ints, b.d_selXY, b.d_selScore, b.d_levelCount,

@@ -116,6 +116,14 @@ struct orb_ctx {
     DevBuf dGeom, dAreaTaps, dLinTaps, dInput, dPyr, dCellKeys, dCellCount, dSort, dNodes, dInts,
         dSelXY, dSelScore, dLevelCount, dLevelKeys, dError, dKps, dDesc, dNOut, dTmpA, dTmpB;
     PinBuf pinIn, pinOut;  // host-pointer entry points only, sized on first use
+    // The quadtree kernel's LDS block holds a level's keys; how many FAST hands over is only known on the
+    // device.  The kernel keeps the largest count it met next to the error word, every batch sends it to
+    // pinSeen without waiting, and the next batches size the block from what has arrived (a level with
+    // more keys than the block holds runs from global memory: slower, same result).
+    PinBuf pinSeen;
+    hipEvent_t evSeen = nullptr;
+    bool seenPending = false;
+    int seenKeys = 0;
     int lastFrames = 0;
     int inputStride = 0;
     const uint8_t* lastImg0 = nullptr;
@@ -474,8 +482,8 @@ static int ensure_buffers(orb_ctx* c, int n) {
     if ((rc = c->dLevelCount.ensure((size_t)n * g.nlevels * 4))) return rc;
     if ((rc = c->dLevelKeys.ensure((size_t)n * g.nlevels * 4))) return rc;
     if (!c->dError.p) {
-        if ((rc = c->dError.ensure(4))) return rc;
-        HIP_TRY(hipMemset(c->dError.p, 0, 4));
+        if ((rc = c->dError.ensure(8))) return rc;  // flag word, then the largest per-level key count seen
+        HIP_TRY(hipMemset(c->dError.p, 0, 8));
     }
     return ORB_OK;
 }
@@ -516,6 +524,15 @@ extern "C" int orb_create(const orb_params* prm, orb_ctx** out) {
         HIP_TRY(hipEventCreateWithFlags(&c->evJoin[i], hipEventDisableTiming));
     }
     HIP_TRY(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->evSeen, hipEventDisableTiming));
+    {
+        int rcPin = c->pinSeen.ensure(64);
+        if (rcPin) {
+            orb_destroy(c);
+            return rcPin;
+        }
+        *(volatile int*)c->pinSeen.p = 0;
+    }
     if (const char* e = getenv("ORBHIP_PARTS")) c->parts = std::max(1, std::min(ORB_MAX_PARTS, atoi(e)));
     // size everything for the largest announced frame and batch now, so steady-state calls allocate nothing
     int rc = compute_geom(c, prm->max_width, prm->max_height);
@@ -547,6 +564,8 @@ extern "C" void orb_destroy(orb_ctx* c) {
     for (DevBuf* b : bufs) b->release();
     c->pinIn.release();
     c->pinOut.release();
+    c->pinSeen.release();
+    if (c->evSeen) (void)hipEventDestroy(c->evSeen);
     if (c->matchState) orb_match_state_free(c->matchState);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     for (int i = 0; i < ORB_MAX_PARTS - 1; i++) {
@@ -581,6 +600,15 @@ extern "C" int orb_get_tables(const orb_ctx* c, float* scale, float* inv_scale, 
     }
     if (umax)
         for (int i = 0; i < 16; i++) umax[i] = c->umax[i];
+    return ORB_OK;
+}
+
+// Sends the device's largest-key-count word towards the host, unless an earlier copy is still under way.
+static int post_seen_keys(orb_ctx* c, hipStream_t st) {
+    if (c->seenPending) return ORB_OK;
+    HIP_TRY(hipMemcpyAsync(c->pinSeen.p, (const int*)c->dError.p + 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(c->evSeen, st));
+    c->seenPending = true;
     return ORB_OK;
 }
 
@@ -631,6 +659,12 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
     b.capPerFrame = cap;
     b.d_nOut = d_nOut;
     b.stream = st;
+    if (c->seenPending && hipEventQuery(c->evSeen) == hipSuccess) {
+        const int seen = *(volatile int*)c->pinSeen.p;
+        c->seenKeys = std::max(c->seenKeys, seen);
+        c->seenPending = false;
+    }
+    b.qtKeysSeen = c->seenKeys;
     c->lastImg0 = d_img0;
     c->lastStride0 = stride;
     c->lastFrameStride0 = frameStride;
@@ -646,7 +680,7 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
         HIP_TRY(hipEventRecord(ev[3], st));
         if ((rc = orb_launch_describe(b))) return rc;
         HIP_TRY(hipEventRecord(ev[4], st));
-        return ORB_OK;
+        return post_seen_keys(c, st);
     }
     const int parts = std::max(1, std::min(c->parts, n / ORB_MIN_PART_FRAMES));
     if (parts > 1) HIP_TRY(hipEventRecord(c->evFork, st));
@@ -673,7 +707,7 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
         HIP_TRY(hipEventRecord(c->evJoin[i - 1], c->aux[i - 1]));
         HIP_TRY(hipStreamWaitEvent(st, c->evJoin[i - 1], 0));
     }
-    return ORB_OK;
+    return post_seen_keys(c, st);
 }
 
 static int read_error_flag(orb_ctx* c) {

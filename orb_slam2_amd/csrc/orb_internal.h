@@ -121,7 +121,8 @@ struct OrbBatch {  // everything one extraction launch sequence needs
     int* d_selScore;            // [frame][outCapFrame]
     int* d_levelCount;          // [frame][nlevels] keypoints kept per level
     int* d_levelKeys;           // [frame][nlevels] keys handed to the quadtree (counted by the FAST kernel)
-    int* d_error;               // flag word, OR of limit bits
+    int* d_error;               // flag word, OR of limit bits; d_error[1] = largest per-level key count seen so far
+    int qtKeysSeen;             // the host's copy of that count (0 = none yet)
     orb_keypoint* d_kps;
     uint8_t* d_desc;
     int capPerFrame;

@@ -166,6 +166,24 @@ def test_extract_batch_equals_single(hip, oracle):
     c.close()
 
 
+def test_extract_after_sparse_frames(hip, oracle):
+    """The quadtree kernel sizes its LDS block from the key counts of earlier batches; a frame with
+    far more keys than any before must come out the same (its levels run from global memory)."""
+    w, h = 640, 480
+    c = _ctx(hip, "fork")
+    e = oracle.Extractor(1000, 1.2, 8, 20, 7, PRESETS["fork"])
+    sparse = np.full((h, w), 100, np.uint8)
+    sparse[100:140, 200:260] = 200  # one bright rectangle: a handful of corners
+    rich = synth_scene(w, h, frame_seed(1, 40))
+    for i, img in enumerate([sparse, sparse, sparse, rich, rich, sparse]):
+        kg, dg = c.extract(img)
+        ko, do = e.extract(img)
+        assert_kps_equal(kg, ko, "frame %d" % i)
+        np.testing.assert_array_equal(dg, do, err_msg="descriptors frame %d" % i)
+    assert len(e.extract(sparse)[0]) < 50 and len(e.extract(rich)[0]) > 900
+    c.close()
+
+
 def test_extract_device_entry_point(hip, oracle):
     import torch
 
