@@ -234,6 +234,65 @@ int orb_bf_query_packed_device(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t*
 int orb_bf_merge_packed_device(int device, const uint64_t* d_gathered, int nshards, int nq, int32_t* d_best_idx,
                                uint16_t* d_best_dist, uint16_t* d_second_dist, void* stream);
 
+/* ---- bag of words: DBoW2 vocabulary tree and SearchByBoW ----------------------- */
+
+/* TemplatedVocabulary<FORB::TDescriptor, FORB> (ORBVocabulary, include/ORBVocabulary.h;
+ * Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h): the tree lives in device memory,
+ * the per-feature descent runs there; the per-word bookkeeping (std::map in the
+ * reference) is host code.  scoring: 0 L1_NORM .. 5 DOT_PRODUCT, weighting:
+ * 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY (BowVector.h:24-45). */
+typedef struct orb_voc orb_voc;
+
+/* loadFromTextFile, TemplatedVocabulary.h:1368-1470: first line "k L scoring
+ * weighting", then one line per node (id = line order from 1): parent id, leaf
+ * flag, 32 descriptor bytes, weight.  Empty lines are skipped. */
+int orb_voc_load_text(const char* path, int device, orb_voc** out);
+/* The same tree from arrays: entry i describes node i + 1 (parent[i] <= i). */
+int orb_voc_create(int k, int L, int scoring, int weighting, const int* parent, const uint8_t* is_leaf,
+                   const uint8_t* desc, const double* weight, int nnodes, int device, orb_voc** out);
+void orb_voc_destroy(orb_voc* voc);
+/* info[6] = k, L, scoring, weighting, nodes (without the root), words. */
+int orb_voc_info(const orb_voc* voc, int info[6]);
+
+/* transform(feature, word_id, weight, nid, levelsup), TemplatedVocabulary.h:1240-1289,
+ * for n descriptors at once: descent by smallest Hamming distance, first child
+ * on ties.  node_id = the node `levelsup` levels above the leaves on the path
+ * (0 = root when levelsup >= L); when the descent ends in a leaf above that
+ * level the reference leaves the value unwritten, here it is the leaf.  Any of
+ * the three outputs may be NULL. */
+int orb_voc_transform(orb_voc* voc, const uint8_t* desc, int n, int levelsup, int* word_id, double* weight,
+                      int* node_id);
+/* Device-resident descriptors (4-byte aligned) and outputs; asynchronous on `stream`. */
+int orb_voc_transform_device(orb_voc* voc, const uint8_t* d_desc, int n, int levelsup, int* d_word_id,
+                             double* d_weight, int* d_node_id, void* stream);
+
+/* transform(features, BowVector&, FeatureVector&, levelsup),
+ * TemplatedVocabulary.h:1136-1206 (KeyFrame::ComputeBoW, src/KeyFrame.cc:145-152,
+ * calls it with levelsup 4).  BowVector: *n_bow (word id ascending, value)
+ * pairs, weighted and normalised as the vocabulary's weighting / scoring
+ * prescribe.  FeatureVector in CSR form: *n_fv node ids ascending, fv_offsets
+ * (n_fv + 1), fv_index = feature numbers in increasing order per node.  Output
+ * arrays hold n entries (fv_offsets n + 1). */
+int orb_voc_bow(orb_voc* voc, const uint8_t* desc, int n, int levelsup, int* bow_id, double* bow_value, int* n_bow,
+                int* fv_node, int* fv_offsets, int* fv_index, int* n_fv);
+
+/* L1Scoring::score, ScoringObject.cpp:23-68 (the score ORBvoc.txt is built
+ * for), of two normalised BowVectors; host, pure. */
+double orb_bow_score_l1(const int* id1, const double* value1, int n1, const int* id2, const double* value2, int n2);
+
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&),
+ * src/ORBmatcher.cc:138-268.  kf_* describe the keyframe: undistorted keypoints
+ * (only .angle is read, :212-216), descriptors, kf_valid[i] != 0 where the
+ * keyframe's map point i exists and is not bad (:170-176), FeatureVector in the
+ * CSR form of orb_voc_bow; f_* the frame.  match_kf[j] (nf entries) = keyframe
+ * feature whose map point frame feature j receives, -1 for none
+ * (vpMapPointMatches).  Up to 8192 features per side. */
+int orb_match_bow(orb_ctx* ctx, const orb_keypoint* kf_keys_un, const uint8_t* kf_desc, const uint8_t* kf_valid, int nkf,
+                  const int* kf_fv_node, const int* kf_fv_offsets, const int* kf_fv_index, int kf_nfv,
+                  const orb_keypoint* f_keys, const uint8_t* f_desc, int nf, const int* f_fv_node,
+                  const int* f_fv_offsets, const int* f_fv_index, int f_nfv, float nnratio, int check_ori,
+                  int* match_kf, int* nmatches);
+
 /* ---- measurement ------------------------------------------------------------ */
 
 /* Stage timing with HIP events recorded on the launch stream around the four

@@ -278,3 +278,81 @@ def compute_image_bounds(cols, rows, K, dist):
     b = np.zeros(4, dtype=np.float32)
     lib().oro_compute_image_bounds(cols, rows, _p(K), _p(dist), _p(b))
     return b
+
+
+# ---- DBoW2 vocabulary tree, bag of words, SearchByBoW ------------------------------------------------
+class Vocabulary:
+    """TemplatedVocabulary<FORB::TDescriptor, FORB> (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise ValueError("vocabulary could not be loaded")
+        self.h = C.c_void_p(handle)
+        info = np.zeros(6, dtype=np.int32)
+        lib().oro_voc_info(self.h, _p(info))
+        self.k, self.L, self.scoring, self.weighting, self.nnodes, self.nwords = (int(v) for v in info)
+
+    @classmethod
+    def from_arrays(cls, k, L, scoring, weighting, parent, leaf, desc, weight):
+        parent = np.ascontiguousarray(parent, dtype=np.int32)
+        leaf = _u8(leaf)
+        desc = _u8(desc)
+        weight = np.ascontiguousarray(weight, dtype=np.float64)
+        lib().oro_voc_from_arrays.restype = C.c_void_p
+        return cls(lib().oro_voc_from_arrays(k, L, scoring, weighting, _p(parent), _p(leaf), _p(desc), _p(weight), len(parent)))
+
+    @classmethod
+    def load(cls, path):
+        lib().oro_voc_load.restype = C.c_void_p
+        return cls(lib().oro_voc_load(str(path).encode()))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().oro_voc_free(self.h)
+            self.h = None
+
+    def transform_features(self, desc, levelsup=4):
+        """Per descriptor: (word id, word weight, node id `levelsup` levels above the leaves)."""
+        desc = _u8(desc).reshape(-1, 32)
+        n = len(desc)
+        word = np.zeros(n, dtype=np.int32)
+        node = np.zeros(n, dtype=np.int32)
+        weight = np.zeros(n, dtype=np.float64)
+        lib().oro_voc_transform_features(self.h, _p(desc), n, levelsup, _p(word), _p(weight), _p(node))
+        return word, weight, node
+
+    def transform(self, desc, levelsup=4):
+        """transform(features, BowVector&, FeatureVector&, levelsup) -> ((ids, values), (nodes, offsets, indices))."""
+        desc = _u8(desc).reshape(-1, 32)
+        n = len(desc)
+        ids = np.zeros(max(n, 1), dtype=np.int32)
+        vals = np.zeros(max(n, 1), dtype=np.float64)
+        nodes = np.zeros(max(n, 1), dtype=np.int32)
+        offs = np.zeros(n + 1, dtype=np.int32)
+        idx = np.zeros(max(n, 1), dtype=np.int32)
+        nb, nn = C.c_int(0), C.c_int(0)
+        lib().oro_voc_bow(self.h, _p(desc), n, levelsup, _p(ids), _p(vals), C.byref(nb), _p(nodes), _p(offs), _p(idx), C.byref(nn))
+        return (ids[: nb.value].copy(), vals[: nb.value].copy()), (
+            nodes[: nn.value].copy(), offs[: nn.value + 1].copy(), idx[: offs[nn.value]].copy())
+
+
+def score_l1(bow1, bow2):
+    """L1Scoring::score of two normalised bag-of-words vectors given as (ids, values)."""
+    i1, v1 = np.ascontiguousarray(bow1[0], np.int32), np.ascontiguousarray(bow1[1], np.float64)
+    i2, v2 = np.ascontiguousarray(bow2[0], np.int32), np.ascontiguousarray(bow2[1], np.float64)
+    lib().oro_score_l1.restype = C.c_double
+    return lib().oro_score_l1(_p(i1), _p(v1), len(i1), _p(i2), _p(v2), len(i2))
+
+
+def search_by_bow(kf_keys_un, kf_desc, kf_valid, kf_fv, f_keys, f_desc, f_fv, nnratio=0.7, check_ori=True):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...): returns (nmatches, matchKF[nF]); kf_fv / f_fv are
+    feature vectors (nodes, offsets, indices) as Vocabulary.transform returns them."""
+    kk = np.ascontiguousarray(kf_keys_un, dtype=KP_DTYPE)
+    fk = np.ascontiguousarray(f_keys, dtype=KP_DTYPE)
+    kd, fd, kv = _u8(kf_desc), _u8(f_desc), _u8(kf_valid)
+    a = [np.ascontiguousarray(x, dtype=np.int32) for x in kf_fv]
+    b = [np.ascontiguousarray(x, dtype=np.int32) for x in f_fv]
+    match = np.full(max(len(fk), 1), -1, dtype=np.int32)
+    n = lib().oro_search_by_bow(_p(kk), _p(kd), _p(kv), _p(a[0]), _p(a[1]), _p(a[2]), len(a[0]), _p(fk), _p(fd), len(fk),
+                                _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]), C.c_float(nnratio), int(check_ori), _p(match))
+    return n, match[: len(fk)]

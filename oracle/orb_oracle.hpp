@@ -15,6 +15,8 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <map>
+#include <string>
 #include <vector>
 
 namespace orbo {
@@ -130,6 +132,30 @@ int searchByProjection(const float* u, const float* v, const float* radius, cons
 // distance to the others (first on ties); *median receives that median.  selfDistance reproduces the fork's
 // DescriptorDistance(d[i], d[i]) at :195 (every distance 0).  Returns -1 for n == 0.
 int distinctiveDescriptor(const uint8_t* desc, int n, bool selfDistance, int* median);
+
+// ---- DBoW2 vocabulary tree and SearchByBoW (orb_oracle_bow.cc) -------------------------
+struct VocNode {
+    int parent = 0;
+    std::vector<int> children;  // in file order
+    uint8_t desc[32] = {0};
+    double weight = 0;
+    int wordId = 0;
+};
+struct Vocabulary {  // TemplatedVocabulary<FORB::TDescriptor, FORB>
+    int k = 0, L = 0, scoring = 0, weighting = 0, nwords = 0;
+    std::vector<VocNode> nodes;  // nodes[0] = root
+    bool loadFromTextFile(const std::string& filename);
+    // nodes 1..nnodes in file order: parent id, leaf flag, descriptor, weight
+    void fromArrays(int k, int L, int scoring, int weighting, const int* parent, const uint8_t* leaf, const uint8_t* desc,
+                    const double* weight, int nnodes);
+    void transformOne(const uint8_t* feature, int levelsup, int* wordId, double* weight, int* nid) const;
+    void transform(const uint8_t* desc, int n, int levelsup, std::map<int, double>& bow,
+                   std::map<int, std::vector<unsigned> >& fv) const;
+};
+double scoreL1(const std::map<int, double>& v1, const std::map<int, double>& v2);
+int searchByBoW(const KeyPoint* kfKeysUn, const uint8_t* kfDesc, const uint8_t* kfValid,
+                const std::map<int, std::vector<unsigned> >& kfFeat, const KeyPoint* fKeys, const uint8_t* fDesc, int nF,
+                const std::map<int, std::vector<unsigned> >& fFeat, float nnratio, bool checkOri, int* matchKF);
 
 void bruteForceTop2(const uint8_t* q, int nq, const uint8_t* db, int64_t nd, int32_t* bestIdx, uint16_t* bestDist,
                     uint16_t* secondDist);

@@ -1,0 +1,252 @@
+// CPU ORACLE — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// Bag-of-words side of the matcher: the vocabulary tree of the vendored DBoW2
+// (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h, BowVector.cpp,
+// FeatureVector.cpp, ScoringObject.cpp) and ORBmatcher::SearchByBoW(KeyFrame*,
+// Frame&, ...) (src/ORBmatcher.cc:138-268), restated with std::map / std::vector
+// exactly as the reference keeps them.
+//
+// PARITY UNPINNED: the reference ships neither a vocabulary file nor any test
+// vector for this part; the tests build small vocabularies of their own.
+//
+// Ruling on an unspecified case: TemplatedVocabulary::transform
+// (TemplatedVocabulary.h:1240-1289) leaves *nid unwritten when the descent
+// reaches a leaf above level L - levelsup (the caller's variable is
+// uninitialised, :1162); here the leaf itself is reported.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+
+#include "orb_oracle.hpp"
+
+namespace orbo {
+
+// TemplatedVocabulary.h:1368-1470.  Lines of the file: "k L scoring weighting", then one line per
+// node (id = line order, from 1): parent, leaf flag, 32 descriptor bytes, weight.
+bool Vocabulary::loadFromTextFile(const std::string& filename) {
+    std::ifstream f(filename.c_str());
+    if (!f.is_open()) return false;
+    std::string s;
+    getline(f, s);
+    std::stringstream ss;
+    ss << s;
+    int n1 = -1, n2 = -1;
+    k = L = -1;
+    ss >> k >> L >> n1 >> n2;
+    if (k < 0 || k > 20 || L < 1 || L > 10 || n1 < 0 || n1 > 5 || n2 < 0 || n2 > 3) return false;
+    scoring = n1;
+    weighting = n2;
+    nodes.clear();
+    nodes.resize(1);
+    nwords = 0;
+    while (!f.eof()) {
+        std::string snode;
+        getline(f, snode);
+        if (snode.empty()) continue;  // (the reference would append a node for a trailing empty line; files end without one)
+        std::stringstream ssnode;
+        ssnode << snode;
+        const int nid = (int)nodes.size();
+        nodes.resize(nodes.size() + 1);
+        int pid = 0, leaf = 0;
+        ssnode >> pid >> leaf;
+        if (pid < 0 || pid >= nid) return false;
+        nodes[nid].parent = pid;
+        nodes[pid].children.push_back(nid);
+        for (int i = 0; i < 32; i++) {
+            int v = 0;
+            ssnode >> v;
+            nodes[nid].desc[i] = (uint8_t)v;
+        }
+        ssnode >> nodes[nid].weight;
+        if (leaf > 0) nodes[nid].wordId = nwords++;
+    }
+    return true;
+}
+
+void Vocabulary::fromArrays(int k_, int L_, int scoring_, int weighting_, const int* parent, const uint8_t* leaf,
+                            const uint8_t* desc, const double* weight, int nnodes) {
+    k = k_;
+    L = L_;
+    scoring = scoring_;
+    weighting = weighting_;
+    nodes.clear();
+    nodes.resize((size_t)nnodes + 1);
+    nwords = 0;
+    for (int i = 1; i <= nnodes; i++) {
+        nodes[i].parent = parent[i - 1];
+        nodes[parent[i - 1]].children.push_back(i);
+        memcpy(nodes[i].desc, desc + (size_t)(i - 1) * 32, 32);
+        nodes[i].weight = weight[i - 1];
+        if (leaf[i - 1]) nodes[i].wordId = nwords++;
+    }
+}
+
+// TemplatedVocabulary.h:1240-1289
+void Vocabulary::transformOne(const uint8_t* feature, int levelsup, int* wordId, double* weight, int* nid) const {
+    const int nidLevel = L - levelsup;
+    int node = -1;
+    if (nidLevel <= 0) node = 0;
+    int finalId = 0, level = 0;
+    do {
+        ++level;
+        const std::vector<int>& ch = nodes[finalId].children;
+        finalId = ch[0];
+        double best = (double)hammingBitHack(feature, nodes[finalId].desc);
+        for (size_t i = 1; i < ch.size(); i++) {
+            const double d = (double)hammingBitHack(feature, nodes[ch[i]].desc);
+            if (d < best) {
+                best = d;
+                finalId = ch[i];
+            }
+        }
+        if (level == nidLevel) node = finalId;
+    } while (!nodes[finalId].children.empty());
+    if (node < 0) node = finalId;  // ruling, see the file header
+    *wordId = nodes[finalId].wordId;
+    *weight = nodes[finalId].weight;
+    *nid = node;
+}
+
+static bool mustNormalize(int scoring, int* norm) {  // ScoringObject.h:85-93 (L1 = 0, L2 = 1)
+    switch (scoring) {
+        case 0: *norm = 0; return true;   // L1_NORM
+        case 1: *norm = 1; return true;   // L2_NORM
+        case 2: *norm = 0; return true;   // CHI_SQUARE
+        case 3: *norm = 0; return true;   // KL
+        case 4: *norm = 0; return true;   // BHATTACHARYYA
+        default: *norm = 0; return false; // DOT_PRODUCT
+    }
+}
+
+// TemplatedVocabulary.h:1136-1206 with BowVector::addWeight / addIfNotExist / normalize
+// (BowVector.cpp:40-95) and FeatureVector::addFeature (FeatureVector.cpp:37-52).
+void Vocabulary::transform(const uint8_t* desc, int n, int levelsup, std::map<int, double>& bow,
+                           std::map<int, std::vector<unsigned> >& fv) const {
+    bow.clear();
+    fv.clear();
+    if (nwords == 0) return;
+    int norm = 0;
+    const bool must = mustNormalize(scoring, &norm);
+    const bool tf = weighting == 0 /*TF_IDF*/ || weighting == 1 /*TF*/;
+    for (int i = 0; i < n; i++) {
+        int id, nid;
+        double w;
+        transformOne(desc + (size_t)i * 32, levelsup, &id, &w, &nid);
+        if (w > 0) {
+            std::map<int, double>::iterator it = bow.find(id);
+            if (it == bow.end()) bow[id] = w;
+            else if (tf) it->second += w;
+            fv[nid].push_back((unsigned)i);
+        }
+    }
+    if (tf && !bow.empty() && !must) {
+        const double nd = (double)bow.size();
+        for (auto& e : bow) e.second /= nd;
+    }
+    if (must) {
+        double s = 0.0;
+        if (norm == 0) {
+            for (auto& e : bow) s += fabs(e.second);
+        } else {
+            for (auto& e : bow) s += e.second * e.second;
+            s = sqrt(s);
+        }
+        if (s > 0.0)
+            for (auto& e : bow) e.second /= s;
+    }
+}
+
+// L1Scoring::score, ScoringObject.cpp:23-68
+double scoreL1(const std::map<int, double>& v1, const std::map<int, double>& v2) {
+    auto a = v1.begin(), b = v2.begin();
+    double score = 0;
+    while (a != v1.end() && b != v2.end()) {
+        if (a->first == b->first) {
+            score += fabs(a->second - b->second) - fabs(a->second) - fabs(b->second);
+            ++a;
+            ++b;
+        } else if (a->first < b->first) {
+            a = v1.lower_bound(b->first);
+        } else {
+            b = v2.lower_bound(a->first);
+        }
+    }
+    return -score / 2.0;
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vector<MapPoint*>&), src/ORBmatcher.cc:138-268.
+// kfValid[i] != 0 stands for "vpMapPointsKF[i] is set and not bad" (:170-176); matchKF[j] receives the
+// keyframe feature whose map point frame feature j takes, or -1 (vpMapPointMatches).
+int searchByBoW(const KeyPoint* kfKeysUn, const uint8_t* kfDesc, const uint8_t* kfValid,
+                const std::map<int, std::vector<unsigned> >& kfFeat, const KeyPoint* fKeys, const uint8_t* fDesc, int nF,
+                const std::map<int, std::vector<unsigned> >& fFeat, float nnratio, bool checkOri, int* matchKF) {
+    const int TH_LOW = 50, HISTO_LENGTH = 30;
+    for (int j = 0; j < nF; j++) matchKF[j] = -1;
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = HISTO_LENGTH / 360.0f;
+    auto KFit = kfFeat.begin();
+    auto Fit = fFeat.begin();
+    while (KFit != kfFeat.end() && Fit != fFeat.end()) {
+        if (KFit->first == Fit->first) {
+            const std::vector<unsigned>& vIndicesKF = KFit->second;
+            const std::vector<unsigned>& vIndicesF = Fit->second;
+            for (size_t iKF = 0; iKF < vIndicesKF.size(); iKF++) {
+                const unsigned realIdxKF = vIndicesKF[iKF];
+                if (!kfValid[realIdxKF]) continue;
+                const uint8_t* dKF = kfDesc + (size_t)realIdxKF * 32;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                for (size_t iF = 0; iF < vIndicesF.size(); iF++) {
+                    const unsigned realIdxF = vIndicesF[iF];
+                    if (matchKF[realIdxF] >= 0) continue;
+                    const int dist = hammingBitHack(dKF, fDesc + (size_t)realIdxF * 32);
+                    if (dist < bestDist1) {
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdxF = (int)realIdxF;
+                    } else if (dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                }
+                if (bestDist1 <= TH_LOW) {
+                    if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                        matchKF[bestIdxF] = (int)realIdxKF;
+                        if (checkOri) {
+                            float rot = kfKeysUn[realIdxKF].angle - fKeys[bestIdxF].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)roundf(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back(bestIdxF);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            KFit++;
+            Fit++;
+        } else if (KFit->first < Fit->first) {
+            KFit = kfFeat.lower_bound(Fit->first);
+        } else {
+            Fit = fFeat.lower_bound(KFit->first);
+        }
+    }
+    if (checkOri) {
+        int counts[HISTO_LENGTH], ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) counts[i] = (int)rotHist[i].size();
+        computeThreeMaxima(counts, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) {
+                matchKF[rotHist[i][j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
+}  // namespace orbo

@@ -198,4 +198,76 @@ int oro_distinctive(const uint8_t* desc, int n, int selfDistance, int* median) {
     return distinctiveDescriptor(desc, n, selfDistance != 0, median);
 }
 
+// ---- vocabulary / bag of words ----------------------------------------------------------
+void* oro_voc_from_arrays(int k, int L, int scoring, int weighting, const int* parent, const uint8_t* leaf,
+                          const uint8_t* desc, const double* weight, int nnodes) {
+    Vocabulary* v = new Vocabulary();
+    v->fromArrays(k, L, scoring, weighting, parent, leaf, desc, weight, nnodes);
+    return v;
+}
+void* oro_voc_load(const char* path) {
+    Vocabulary* v = new Vocabulary();
+    if (!v->loadFromTextFile(path)) {
+        delete v;
+        return nullptr;
+    }
+    return v;
+}
+void oro_voc_free(void* h) { delete (Vocabulary*)h; }
+void oro_voc_info(void* h, int* out6) {
+    const Vocabulary* v = (const Vocabulary*)h;
+    out6[0] = v->k;
+    out6[1] = v->L;
+    out6[2] = v->scoring;
+    out6[3] = v->weighting;
+    out6[4] = (int)v->nodes.size() - 1;
+    out6[5] = v->nwords;
+}
+void oro_voc_transform_features(void* h, const uint8_t* desc, int n, int levelsup, int* word, double* weight, int* node) {
+    const Vocabulary* v = (const Vocabulary*)h;
+    for (int i = 0; i < n; i++) v->transformOne(desc + (size_t)i * 32, levelsup, &word[i], &weight[i], &node[i]);
+}
+static std::map<int, std::vector<unsigned> > fv_from_csr(const int* nodes, const int* offsets, const int* idx, int nn) {
+    std::map<int, std::vector<unsigned> > fv;
+    for (int a = 0; a < nn; a++) fv[nodes[a]].assign(idx + offsets[a], idx + offsets[a + 1]);
+    return fv;
+}
+// Bag-of-words vector (ids ascending, values) and feature vector (CSR: node ids ascending, offsets, feature
+// indices) of n descriptors; the output arrays hold up to n (offsets n + 1) entries.
+void oro_voc_bow(void* h, const uint8_t* desc, int n, int levelsup, int* bowIds, double* bowVals, int* nBow, int* fvNodes,
+                 int* fvOffsets, int* fvIdx, int* nFvNodes) {
+    const Vocabulary* v = (const Vocabulary*)h;
+    std::map<int, double> bow;
+    std::map<int, std::vector<unsigned> > fv;
+    v->transform(desc, n, levelsup, bow, fv);
+    int i = 0;
+    for (auto& e : bow) {
+        bowIds[i] = e.first;
+        bowVals[i] = e.second;
+        i++;
+    }
+    *nBow = i;
+    int a = 0, o = 0;
+    fvOffsets[0] = 0;
+    for (auto& e : fv) {
+        fvNodes[a] = e.first;
+        for (unsigned f : e.second) fvIdx[o++] = (int)f;
+        fvOffsets[++a] = o;
+    }
+    *nFvNodes = a;
+}
+double oro_score_l1(const int* ids1, const double* vals1, int n1, const int* ids2, const double* vals2, int n2) {
+    std::map<int, double> a, b;
+    for (int i = 0; i < n1; i++) a[ids1[i]] = vals1[i];
+    for (int i = 0; i < n2; i++) b[ids2[i]] = vals2[i];
+    return scoreL1(a, b);
+}
+int oro_search_by_bow(const KeyPoint* kfKeysUn, const uint8_t* kfDesc, const uint8_t* kfValid, const int* kfNodes,
+                      const int* kfOffsets, const int* kfIdx, int kfNN, const KeyPoint* fKeys, const uint8_t* fDesc, int nF,
+                      const int* fNodes, const int* fOffsets, const int* fIdx, int fNN, float nnratio, int checkOri,
+                      int* matchKF) {
+    return searchByBoW(kfKeysUn, kfDesc, kfValid, fv_from_csr(kfNodes, kfOffsets, kfIdx, kfNN), fKeys, fDesc, nF,
+                       fv_from_csr(fNodes, fOffsets, fIdx, fNN), nnratio, checkOri != 0, matchKF);
+}
+
 }  // extern "C"

@@ -32,6 +32,8 @@ EXPORTS = [
     "orb_enable_stage_timing", "orb_get_stage_timings", "orb_last_error", "orb_version",
     "orb_distinctive_descriptors", "orb_distinctive_descriptors_device",
     "orb_undistort_keypoints", "orb_undistort_keypoints_device", "orb_compute_image_bounds", "orb_set_image_bounds",
+    "orb_voc_load_text", "orb_voc_create", "orb_voc_destroy", "orb_voc_info", "orb_voc_transform",
+    "orb_voc_transform_device", "orb_voc_bow", "orb_bow_score_l1", "orb_match_bow",
 ]
 
 
@@ -283,6 +285,25 @@ class Context:
                                                         _dp(d_median) if d_median is not None else None, _stream(stream)))
 
 
+    def match_bow(self, kf_keys_un, kf_desc, kf_valid, kf_fv, f_keys, f_desc, f_fv, nnratio=0.7, check_ori=True):
+        """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (src/ORBmatcher.cc:138-268).  kf_fv / f_fv are
+        feature vectors (nodes, offsets, indices) as Vocabulary.transform returns them; kf_valid marks the
+        keyframe features that hold a usable map point.  Returns (nmatches, match_kf[nf])."""
+        kk = np.ascontiguousarray(kf_keys_un, KP_DTYPE)
+        fk = np.ascontiguousarray(f_keys, KP_DTYPE)
+        kd = np.ascontiguousarray(kf_desc, np.uint8)
+        fd = np.ascontiguousarray(f_desc, np.uint8)
+        kv = np.ascontiguousarray(kf_valid, np.uint8)
+        a = [np.ascontiguousarray(x, np.int32) for x in kf_fv]
+        b = [np.ascontiguousarray(x, np.int32) for x in f_fv]
+        match = np.full(max(len(fk), 1), -1, np.int32)
+        nm = C.c_int(0)
+        _check(lib().orb_match_bow(self.h, _p(kk), _p(kd), _p(kv), len(kk), _p(a[0]), _p(a[1]), _p(a[2]), len(a[0]), _p(fk),
+                                   _p(fd), len(fk), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]), C.c_float(nnratio),
+                                   int(check_ori), _p(match), C.byref(nm)))
+        return nm.value, match[: len(fk)]
+
+
 class BruteForce:
     """One shard of a brute-force descriptor database on one device."""
 
@@ -323,3 +344,77 @@ class BruteForce:
 
 def merge_packed_device(device, d_gathered, nshards, nq, d_idx, d_best, d_second, stream=None):
     _check(lib().orb_bf_merge_packed_device(device, _dp(d_gathered), nshards, nq, _dp(d_idx), _dp(d_best), _dp(d_second), _stream(stream)))
+
+
+class Vocabulary:
+    """ORBVocabulary = TemplatedVocabulary<FORB::TDescriptor, FORB> with the tree on one device."""
+
+    def __init__(self, handle):
+        self.h = handle
+        self._destroy = lib().orb_voc_destroy
+        info = (C.c_int * 6)()
+        _check(lib().orb_voc_info(self.h, info))
+        self.k, self.L, self.scoring, self.weighting, self.nnodes, self.nwords = (int(v) for v in info)
+
+    @classmethod
+    def load(cls, path, device=0):
+        """loadFromTextFile (the format of Vocabulary/ORBvoc.txt)."""
+        h = C.c_void_p()
+        _check(lib().orb_voc_load_text(str(path).encode(), device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, k, L, scoring, weighting, parent, leaf, desc, weight, device=0):
+        parent = np.ascontiguousarray(parent, np.int32)
+        leaf = np.ascontiguousarray(leaf, np.uint8)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        weight = np.ascontiguousarray(weight, np.float64)
+        h = C.c_void_p()
+        _check(lib().orb_voc_create(k, L, scoring, weighting, _p(parent), _p(leaf), _p(desc), _p(weight), len(parent), device,
+                                    C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if getattr(self, "h", None) and self.h:
+            self._destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def transform_features(self, desc, levelsup=4):
+        """Per descriptor: (word id, word weight, node id `levelsup` levels above the leaves)."""
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(desc)
+        word = np.zeros(n, np.int32)
+        node = np.zeros(n, np.int32)
+        weight = np.zeros(n, np.float64)
+        _check(lib().orb_voc_transform(self.h, _p(desc), n, levelsup, _p(word), _p(weight), _p(node)))
+        return word, weight, node
+
+    def transform_features_device(self, d_desc, levelsup, d_word, d_weight, d_node, stream=None):
+        """d_desc uint8 [n, 32]; outputs int32 [n], float64 [n], int32 [n] CUDA tensors (any may be None)."""
+        _check(lib().orb_voc_transform_device(self.h, _dp(d_desc), d_desc.shape[0], levelsup, _dp(d_word), _dp(d_weight),
+                                              _dp(d_node), _stream(stream)))
+
+    def transform(self, desc, levelsup=4):
+        """transform(features, BowVector&, FeatureVector&, levelsup) -> ((ids, values), (nodes, offsets, indices))."""
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        n = len(desc)
+        ids = np.zeros(max(n, 1), np.int32)
+        vals = np.zeros(max(n, 1), np.float64)
+        nodes = np.zeros(max(n, 1), np.int32)
+        offs = np.zeros(n + 1, np.int32)
+        idx = np.zeros(max(n, 1), np.int32)
+        nb, nn = C.c_int(0), C.c_int(0)
+        _check(lib().orb_voc_bow(self.h, _p(desc), n, levelsup, _p(ids), _p(vals), C.byref(nb), _p(nodes), _p(offs), _p(idx),
+                                 C.byref(nn)))
+        return (ids[: nb.value].copy(), vals[: nb.value].copy()), (
+            nodes[: nn.value].copy(), offs[: nn.value + 1].copy(), idx[: offs[nn.value]].copy())
+
+
+def bow_score_l1(bow1, bow2):
+    """L1Scoring::score of two normalised bag-of-words vectors given as (ids, values)."""
+    i1, v1 = np.ascontiguousarray(bow1[0], np.int32), np.ascontiguousarray(bow1[1], np.float64)
+    i2, v2 = np.ascontiguousarray(bow2[0], np.int32), np.ascontiguousarray(bow2[1], np.float64)
+    lib().orb_bow_score_l1.restype = C.c_double
+    return lib().orb_bow_score_l1(_p(i1), _p(v1), len(i1), _p(i2), _p(v2), len(i2))

@@ -135,6 +135,8 @@ struct orb_ctx {
     float bounds[4] = {0, 0, 0, 0};
     // matcher scratch lives in kernels_match.hip
     void* matchState = nullptr;
+    // bag-of-words matcher scratch lives in kernels_bow.hip
+    void* bowState = nullptr;
     // stage timing: ring of event sets, one set (5 events) per recorded batch
     bool timing = false;
     std::vector<hipEvent_t> events;
@@ -143,12 +145,14 @@ struct orb_ctx {
 #define ORB_EV_RING 64
 
 void orb_match_state_free(void* p);
+void orb_bow_state_free(void* p);
 
 // accessors for the matcher's translation unit
 int orb_ctx_device(const orb_ctx* c) { return c->prm.device; }
 unsigned orb_ctx_quirks(const orb_ctx* c) { return c->prm.quirks; }
 int orb_ctx_max_batch(const orb_ctx* c) { return c->prm.max_batch; }
 void** orb_ctx_match_state(orb_ctx* c) { return &c->matchState; }
+void** orb_ctx_bow_state(orb_ctx* c) { return &c->bowState; }
 int orb_ctx_get_bounds(const orb_ctx* c, float b[4]) {
     if (c->haveBounds) memcpy(b, c->bounds, sizeof(c->bounds));
     return c->haveBounds ? 1 : 0;
@@ -567,6 +571,7 @@ extern "C" void orb_destroy(orb_ctx* c) {
     c->pinSeen.release();
     if (c->evSeen) (void)hipEventDestroy(c->evSeen);
     if (c->matchState) orb_match_state_free(c->matchState);
+    if (c->bowState) orb_bow_state_free(c->bowState);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     for (int i = 0; i < ORB_MAX_PARTS - 1; i++) {
         if (c->evJoin[i]) (void)hipEventDestroy(c->evJoin[i]);

@@ -88,3 +88,46 @@ def synth_queries(db, nq, seed, dup_frac=0.1, max_flips=60):
             for b in bits[i, : flips[i]]:
                 q[i, b >> 3] ^= np.uint8(1 << (b & 7))
     return q
+
+
+def synth_vocabulary(k, L, seed, prune=0.0, stop=0.0):
+    """A vocabulary tree in the shape DBoW2 stores (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1368-1470):
+    arrays over nodes 1..n in file order (breadth first, a parent before its children): parent id, leaf flag,
+    32-byte descriptor, weight.  A child's descriptor is its parent's with random bits flipped, fewer the
+    deeper the level, so the descent by Hamming distance is meaningful.  `prune` = fraction of inner nodes
+    cut to a leaf early or given fewer than k children; `stop` = fraction of words with weight 0."""
+    r = np.random.default_rng(seed)
+    parent, leaf, desc, weight = [], [], [], []
+    level_nodes = [(0, np.zeros(32, np.uint8))]  # (id, descriptor) of the current level; the root has none
+    next_id = 1
+    for depth in range(1, L + 1):
+        new_level = []
+        flips = max(4, 128 >> (depth - 1))
+        for pid, pdesc in level_nodes:
+            nchild = k
+            if pid != 0 and prune > 0 and r.random() < prune:
+                nchild = int(r.integers(1, k)) if k > 1 else 1
+            for _ in range(nchild):
+                bits = np.unpackbits(pdesc if pid else r.integers(0, 256, 32, dtype=np.uint8))
+                idx = r.choice(256, size=flips, replace=False)
+                bits[idx] ^= 1
+                d = np.packbits(bits)
+                is_leaf = depth == L or (prune > 0 and r.random() < prune * 0.5)
+                parent.append(pid)
+                leaf.append(1 if is_leaf else 0)
+                desc.append(d)
+                weight.append((0.0 if r.random() < stop else float(r.random() * 5 + 0.01)) if is_leaf else 0.0)
+                if not is_leaf:
+                    new_level.append((next_id, d))
+                next_id += 1
+        level_nodes = new_level
+    return (np.array(parent, np.int32), np.array(leaf, np.uint8), np.array(desc, np.uint8).reshape(-1, 32),
+            np.array(weight, np.float64))
+
+
+def write_vocabulary_text(path, k, L, scoring, weighting, parent, leaf, desc, weight):
+    """The text format of saveToTextFile (TemplatedVocabulary.h:1474-1497), the one ORBvoc.txt is in."""
+    with open(path, "w") as f:
+        f.write("%d %d  %d %d\n" % (k, L, scoring, weighting))
+        for i in range(len(parent)):
+            f.write("%d %d %s %s\n" % (parent[i], leaf[i], " ".join(str(int(b)) for b in desc[i]) + " ", repr(float(weight[i]))))
