@@ -7,6 +7,8 @@
 //   in.bin : int32 w, h, nfeatures, window; float nnratio; then 2 * w*h bytes (frame A, frame B)
 //   environment ORBDEMO_CAMERA="fx,fy,cx,cy,k1,k2,p1,p2,k3" replaces the default pinhole camera
 //   (fx = fy = 500, principal point at the image centre, no distortion)
+//   environment ORBDEMO_VOC=<vocabulary text file> adds Frame::ComputeBoW on both frames, the L1 score of
+//   their bag-of-words vectors and ORBmatcher::SearchByBoW with frame A in the keyframe's place
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -47,10 +49,13 @@ int main(int argc, char** argv) {
             dist = cv::Mat(c[8] != 0.f ? 5 : 4, 1, CV_32F);  // src/Tracking.cc:76-88: k3 only when non-zero
             for (int i = 0; i < dist.rows; i++) dist.at<float>(i) = c[4 + i];
         }
-        Frame F1(imA, 0.0, &ext, nullptr, K, dist, 40.f, 35.f);
+        ORBVocabulary voc;
+        const char* vocPath = getenv("ORBDEMO_VOC");
+        if (vocPath && !voc.loadFromTextFile(vocPath)) return 8;
+        Frame F1(imA, 0.0, &ext, vocPath ? &voc : nullptr, K, dist, 40.f, 35.f);
         std::vector<cv::Mat> pyrA = ext.mvImagePyramid;
         for (cv::Mat& m : pyrA) m = m.clone();
-        Frame F2(imB, 1.0, &ext, nullptr, K, dist, 40.f, 35.f);
+        Frame F2(imB, 1.0, &ext, vocPath ? &voc : nullptr, K, dist, 40.f, 35.f);
 
         ORBmatcher matcher(nnratio, true);
         std::vector<cv::Point2f> prev(F1.mvKeysUn.size());
@@ -83,7 +88,23 @@ int main(int argc, char** argv) {
 
         FILE* fo = fopen(argv[2], "wb");
         if (!fo) return 6;
-        const int counts[8] = {F1.N, F2.N, nInit, nProj, (int)area.size(), dd, (int)pyrA.size(), 1};
+        // bag of words: every 7th map point of frame A is bad, the ones without observations still count (:170-176)
+        int nBow = -1;
+        double bowScore = 0;
+        std::vector<int> bowMatch(F2.N, -1);
+        if (vocPath) {
+            F1.ComputeBoW();
+            F2.ComputeBoW();
+            bowScore = voc.score(F1.mBowVec, F2.mBowVec);
+            for (int i = 0; i < F1.N; i += 7) F1.mvpMapPoints[i]->SetBadFlag();
+            std::vector<MapPoint*> vpMatches;
+            nBow = matcher.SearchByBoW(F1, F2, vpMatches);
+            for (int i2 = 0; i2 < F2.N; i2++)
+                for (int i = 0; i < F1.N && vpMatches[i2]; i++)
+                    if (vpMatches[i2] == F1.mvpMapPoints[i]) { bowMatch[i2] = i; break; }
+        }
+
+        const int counts[8] = {F1.N, F2.N, nInit, nProj, (int)area.size(), dd, (int)pyrA.size(), vocPath ? 2 : 1};
         put(fo, counts, 8);
         put(fo, F1.mvKeys.data(), F1.mvKeys.size());
         for (int i = 0; i < F1.N; i++) put(fo, F1.mDescriptors.ptr<unsigned char>(i), 32);
@@ -104,6 +125,20 @@ int main(int argc, char** argv) {
         put(fo, F2.mvKeysUn.data(), F2.mvKeysUn.size());
         const float bounds[4] = {Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY};
         put(fo, bounds, 4);
+        if (vocPath) {  // counts[7] == 2: match count, per-feature matches, score, both bag-of-words vectors
+            put(fo, &nBow, 1);
+            put(fo, bowMatch.data(), bowMatch.size());
+            put(fo, &bowScore, 1);
+            for (Frame* F : {&F1, &F2}) {
+                const int n = (int)F->mBowVec.size();
+                put(fo, &n, 1);
+                for (DBoW2::BowVector::const_iterator it = F->mBowVec.begin(); it != F->mBowVec.end(); ++it) {
+                    const int id = (int)it->first;
+                    put(fo, &id, 1);
+                    put(fo, &it->second, 1);
+                }
+            }
+        }
         fclose(fo);
         for (MapPoint* p : owned) delete p;
     } catch (const std::exception& e) {

@@ -29,7 +29,7 @@ Frame::Frame(const Frame& f)
       mpORBextractorRight(f.mpORBextractorRight), mTimeStamp(f.mTimeStamp), mK(f.mK.clone()),
       mDistCoef(f.mDistCoef.clone()), mbf(f.mbf), mb(f.mb), mThDepth(f.mThDepth), N(f.N), mvKeys(f.mvKeys),
       mvKeysRight(f.mvKeysRight), mvKeysUn(f.mvKeysUn), mvuRight(f.mvuRight), mvDepth(f.mvDepth),
-      mDescriptors(f.mDescriptors.clone()), mDescriptorsRight(f.mDescriptorsRight.clone()),
+      mBowVec(f.mBowVec), mFeatVec(f.mFeatVec), mDescriptors(f.mDescriptors.clone()), mDescriptorsRight(f.mDescriptorsRight.clone()),
       mvpMapPoints(f.mvpMapPoints), mvbOutlier(f.mvbOutlier), mnId(f.mnId), mpReferenceKF(f.mpReferenceKF),
       mnScaleLevels(f.mnScaleLevels), mfScaleFactor(f.mfScaleFactor), mfLogScaleFactor(f.mfLogScaleFactor),
       mvScaleFactors(f.mvScaleFactors), mvInvScaleFactors(f.mvInvScaleFactors), mvLevelSigma2(f.mvLevelSigma2),
@@ -37,6 +37,11 @@ Frame::Frame(const Frame& f)
     for (int i = 0; i < FRAME_GRID_COLS; i++)
         for (int j = 0; j < FRAME_GRID_ROWS; j++) mGrid[i][j] = f.mGrid[i][j];
     if (!f.mTcw.empty()) SetPose(f.mTcw);
+}
+
+// Body as KeyFrame::ComputeBoW of the reference (src/KeyFrame.cc:145-152): four levels up from the leaves.
+void Frame::ComputeBoW() {
+    if (mBowVec.empty() && mpORBvocabulary) mpORBvocabulary->transform(mDescriptors, mBowVec, mFeatVec, 4);
 }
 
 Frame::Frame(const cv::Mat& imGray, const double& timeStamp, ORBextractor* extractor, ORBVocabulary* voc, cv::Mat& K,

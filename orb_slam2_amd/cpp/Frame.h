@@ -1,8 +1,8 @@
 // Drop-in for the part of include/Frame.h of the reference that the ORB front
 // end touches: the monocular constructor, ExtractORB, the 64x48 bucket grid
-// with GetFeaturesInArea, and the public members ORBmatcher reads.  Pose
-// graph, bag-of-words and stereo members are kept as declarations so that the
-// class stays source-compatible with its callers.
+// with GetFeaturesInArea, ComputeBoW, and the public members ORBmatcher reads.
+// Pose graph and stereo members are kept as declarations so that the class
+// stays source-compatible with its callers.
 #ifndef FRAME_H
 #define FRAME_H
 
@@ -12,15 +12,14 @@
 #include "ORBextractor.h"
 #include "cv_compat.h"
 
+#include "ORBVocabulary.h"
 #ifdef ORB_SLAM2_FULL_TREE
 #include "KeyFrame.h"
 #include "MapPoint.h"
-#include "ORBVocabulary.h"
 #else
 #include "MapPointCompat.h"
 namespace ORB_SLAM2 {
 class KeyFrame;
-struct ORBVocabulary;  // opaque here
 }  // namespace ORB_SLAM2
 #endif
 
@@ -39,6 +38,8 @@ public:
           cv::Mat& distCoef, const float& bf, const float& thDepth);
 
     void ExtractORB(int flag, const cv::Mat& im);  // src/Frame.cc:71-77
+    // include/Frame.h:36 (declared only in the fork; body as KeyFrame::ComputeBoW, src/KeyFrame.cc:145-152)
+    void ComputeBoW();
     void SetPose(cv::Mat Tcw);
     bool PosInGrid(const cv::KeyPoint& kp, int& posX, int& posY);
     // src/Frame.cc:86-144.  Host-side accessor for callers that want the index list itself;
@@ -57,6 +58,8 @@ public:
     int N;
     std::vector<cv::KeyPoint> mvKeys, mvKeysRight, mvKeysUn;
     std::vector<float> mvuRight, mvDepth;
+    DBoW2::BowVector mBowVec;        // include/Frame.h:87
+    DBoW2::FeatureVector mFeatVec;   // include/Frame.h:88
     cv::Mat mDescriptors, mDescriptorsRight;
     std::vector<MapPoint*> mvpMapPoints;
     std::vector<bool> mvbOutlier;

@@ -1,5 +1,6 @@
-// Stand-alone stand-in for the three MapPoint accessors that
-// ORBmatcher::SearchByProjection reads (src/ORBmatcher.cc:310,337,346).  When
+// Stand-alone stand-in for the MapPoint accessors that ORBmatcher reads
+// (GetWorldPos, GetDescriptor, Observations: src/ORBmatcher.cc:310,337,346;
+// isBad: :175).  When
 // the drop-in is compiled inside the reference tree, define
 // ORB_SLAM2_FULL_TREE and the real MapPoint.h is used instead.
 #pragma once
@@ -8,7 +9,7 @@
 namespace ORB_SLAM2 {
 class MapPoint {
 public:
-    MapPoint(float x, float y, float z, const unsigned char desc[32], int nObs) : mnObs(nObs) {
+    MapPoint(float x, float y, float z, const unsigned char desc[32], int nObs) : mnObs(nObs), mbBad(false) {
         mWorldPos.create(3, 1, CV_32F);
         mWorldPos.at<float>(0) = x;
         mWorldPos.at<float>(1) = y;
@@ -19,9 +20,12 @@ public:
     cv::Mat GetWorldPos() { return mWorldPos.clone(); }
     cv::Mat GetDescriptor() { return mDescriptor.clone(); }
     int Observations() { return mnObs; }
+    bool isBad() { return mbBad; }
+    void SetBadFlag() { mbBad = true; }
 
 private:
     cv::Mat mWorldPos, mDescriptor;
     int mnObs;
+    bool mbBad;
 };
 }  // namespace ORB_SLAM2

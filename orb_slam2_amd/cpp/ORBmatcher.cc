@@ -133,6 +133,55 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
     return nmatches;
 }
 
+// FeatureVector -> CSR arrays (node ids ascend in map order)
+static void flatten(const DBoW2::FeatureVector& fv, std::vector<int>& node, std::vector<int>& off, std::vector<int>& idx) {
+    node.clear();
+    idx.clear();
+    off.assign(1, 0);
+    for (DBoW2::FeatureVector::const_iterator it = fv.begin(); it != fv.end(); ++it) {
+        node.push_back((int)it->first);
+        idx.insert(idx.end(), it->second.begin(), it->second.end());
+        off.push_back((int)idx.size());
+    }
+}
+
+// src/ORBmatcher.cc:138-268; MapPoint::isBad (:175) is asked on the host, the search runs on the device.
+int ORBmatcher::SearchByBoWImpl(const std::vector<MapPoint*>& vpMapPointsKF, const std::vector<cv::KeyPoint>& vKeysUnKF,
+                                const cv::Mat& descriptorsKF, const DBoW2::FeatureVector& vFeatVecKF, Frame& F,
+                                std::vector<MapPoint*>& vpMapPointMatches) {
+    vpMapPointMatches = std::vector<MapPoint*>(F.N, static_cast<MapPoint*>(NULL));
+    const int nkf = (int)vKeysUnKF.size();
+    if (nkf == 0 || F.N == 0) return 0;
+    std::vector<unsigned char> valid(nkf, 0), tk, tf;
+    for (int i = 0; i < nkf; i++) {
+        MapPoint* pMP = i < (int)vpMapPointsKF.size() ? vpMapPointsKF[i] : static_cast<MapPoint*>(NULL);
+        valid[i] = (pMP && !pMP->isBad()) ? 1 : 0;
+    }
+    std::vector<int> kn, ko, ki, fn, fo, fi, match(F.N, -1);
+    flatten(vFeatVecKF, kn, ko, ki);
+    flatten(F.mFeatVec, fn, fo, fi);
+    int nmatches = 0;
+    orb_ctx* ctx = F.mpORBextractorLeft->Context();
+    if (orb_match_bow(ctx, (const orb_keypoint*)vKeysUnKF.data(), packed(descriptorsKF, tk), valid.data(), nkf, kn.data(),
+                      ko.data(), ki.data(), (int)kn.size(), (const orb_keypoint*)F.mvKeys.data(), packed(F.mDescriptors, tf),
+                      F.N, fn.data(), fo.data(), fi.data(), (int)fn.size(), mfNNratio, mbCheckOrientation ? 1 : 0,
+                      match.data(), &nmatches))
+        fail("orb_match_bow");
+    for (int j = 0; j < F.N; j++)
+        if (match[j] >= 0) vpMapPointMatches[j] = vpMapPointsKF[match[j]];
+    return nmatches;
+}
+
+int ORBmatcher::SearchByBoW(const Frame& KF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches) {
+    return SearchByBoWImpl(KF.mvpMapPoints, KF.mvKeysUn, KF.mDescriptors, KF.mFeatVec, F, vpMapPointMatches);
+}
+
+#ifdef ORB_SLAM2_FULL_TREE
+int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches) {
+    return SearchByBoWImpl(pKF->GetMapPointMatches(), pKF->mvKeysUn, pKF->mDescriptors, pKF->mFeatVec, F, vpMapPointMatches);
+}
+#endif
+
 // src/ORBmatcher.cc:413-454 (host helper kept for callers; the kernels carry their own copy).
 void ORBmatcher::ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {
     int max1 = 0, max2 = 0, max3 = 0;

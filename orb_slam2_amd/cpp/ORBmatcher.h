@@ -3,8 +3,11 @@
 // Frame&, th, bMono), DescriptorDistance) run on the GPU through liborbhip.
 // The overloads the fork only declares (include/ORBmatcher.h:39,75,90,110,143,
 // 160,171,184) or defines with an empty body stay declared here, unimplemented,
-// exactly as callers of the fork see them; SearchByBoW(KeyFrame*, Frame&, ...)
-// needs the DBoW2 feature vectors and is not part of this front end.
+// exactly as callers of the fork see them.  SearchByBoW(KeyFrame*, Frame&, ...)
+// (src/ORBmatcher.cc:138-268) runs on the GPU as well; outside the reference's
+// source tree, where KeyFrame is not defined, the same search is offered with a
+// Frame in the keyframe's place (it reads the members both classes share:
+// map points, undistorted keypoints, descriptors, feature vector).
 #ifndef ORBMATCHER_H
 #define ORBMATCHER_H
 
@@ -33,13 +36,16 @@ public:
     // moving forward, [0, nLastOctave] when moving backward)
     int SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th, const bool bMono);
 
+    // src/ORBmatcher.cc:138-268
+    int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches);
+    int SearchByBoW(const Frame& KF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches);
+
     // declared by the reference, defined nowhere in it: kept for source compatibility
     int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3);
     int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound,
                            const float th, const int ORBdist);
     int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints,
                            std::vector<MapPoint*>& vpMatched, int th);
-    int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches);
     int SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, std::vector<MapPoint*>& vpMatches12);
     int SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12,
                                std::vector<std::pair<size_t, size_t> >& vMatchedPairs, const bool bOnlyStereo);
@@ -55,6 +61,9 @@ public:
     static const int HISTO_LENGTH;
 
 protected:
+    int SearchByBoWImpl(const std::vector<MapPoint*>& vpMapPointsKF, const std::vector<cv::KeyPoint>& vKeysUnKF,
+                        const cv::Mat& descriptorsKF, const DBoW2::FeatureVector& vFeatVecKF, Frame& F,
+                        std::vector<MapPoint*>& vpMapPointMatches);
     void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3);
 
     float mfNNratio;

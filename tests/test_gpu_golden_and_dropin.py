@@ -191,6 +191,72 @@ def test_cpp_dropin_demo_with_lens_distortion(oracle, tmp_path):
         oracle.set_image_bounds(None)
 
 
+def test_cpp_dropin_demo_with_vocabulary(oracle, tmp_path):
+    """The drop-in ORBVocabulary (text file loader), Frame::ComputeBoW, the L1 score and
+    ORBmatcher::SearchByBoW with frame A in the keyframe's place."""
+    from orb_slam2_amd.synth import synth_vocabulary, write_vocabulary_text
+
+    exe = os.path.join(ROOT, "examples", "orb_demo")
+    quirks = oracle.QUIRKS_FORK
+    w, h, nf, window, ratio = 640, 480, 1000, 100, 0.8
+    a = synth_scene(w, h, frame_seed(1, 11))
+    b = synth_scene(w, h, frame_seed(1, 11), shift=(2, 1), noise_seed=555)
+    arrays = synth_vocabulary(10, 5, seed=8, prune=0.05, stop=0.02)
+    voc_path = tmp_path / "voc.txt"
+    write_vocabulary_text(voc_path, 10, 5, 0, 0, *arrays)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<iiiif", w, h, nf, window, ratio))
+        f.write(a.tobytes())
+        f.write(b.tobytes())
+    env = dict(os.environ, ORBHIP_QUIRKS=str(quirks), ORBDEMO_VOC=str(voc_path))
+    subprocess.check_call([exe, fin, fout], env=env, timeout=120)
+    raw = open(fout, "rb").read()
+    cnt = np.frombuffer(raw, np.int32, 8)
+    n1, n2, n_init, n_proj, n_area, dd, nlev, tail = (int(v) for v in cnt)
+    assert tail == 2
+    off = 32
+
+    def take(dtype, n):
+        nonlocal off
+        arr = np.frombuffer(raw, dtype, n, off)
+        off += arr.nbytes
+        return arr
+
+    KP = oracle.KP_DTYPE
+    take(KP, n1); take(np.uint8, n1 * 32); take(KP, n2); take(np.uint8, n2 * 32)
+    take(np.int32, n1); take(np.float32, 2 * n1); take(np.int32, n2); take(np.int32, n_area)
+    for l in range(nlev):
+        wl, hl = (int(v) for v in take(np.int32, 2))
+        take(np.uint8, wl * hl)
+    k1u = take(KP, n1); take(KP, n2); take(np.float32, 4)
+    n_bow = int(take(np.int32, 1)[0])
+    bow_match = take(np.int32, n2)
+    score = float(take(np.float64, 1)[0])
+    bows = []
+    pair = np.dtype([("id", "<i4"), ("v", "<f8")])
+    for _ in range(2):
+        n = int(take(np.int32, 1)[0])
+        rec = np.frombuffer(raw, pair, n, off)
+        off += n * 12
+        bows.append((rec["id"].copy(), rec["v"].copy()))
+    assert off == len(raw)
+    e = oracle.Extractor(nf, 1.2, 8, 20, 7, quirks)
+    ko1, do1 = e.extract(a)
+    ko2, do2 = e.extract(b)
+    v = oracle.Vocabulary.load(voc_path)
+    bow1, fv1 = v.transform(do1, 4)
+    bow2, fv2 = v.transform(do2, 4)
+    for got, ref in zip(bows, (bow1, bow2)):
+        np.testing.assert_array_equal(got[0], ref[0])
+        np.testing.assert_array_equal(got[1], ref[1])
+    assert score == oracle.score_l1(bow1, bow2)
+    valid = (np.arange(n1) % 7 != 0).astype(np.uint8)
+    n_ref, m_ref = oracle.search_by_bow(k1u, do1, valid, fv1, ko2, do2, fv2, ratio, True)
+    assert n_bow == n_ref and n_ref > 50
+    np.testing.assert_array_equal(bow_match, m_ref)
+
+
 def test_properties_at_full_sizes(hip):
     """Config-scale checks that need no oracle run: (a) every descriptor's distance to itself is 0 and the
     brute-force scan of a set against itself returns the identity with second >= best; (b) extraction is

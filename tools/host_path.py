@@ -13,7 +13,7 @@ import torch  # noqa: F401  (loads the HIP runtime before liborbhip)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from orb_slam2_amd import binding  # noqa: E402
-from orb_slam2_amd.synth import frame_seed, synth_scene  # noqa: E402
+from orb_slam2_amd.synth import frame_seed, synth_scene, synth_vocabulary  # noqa: E402
 
 
 def timed(fn, steps, warmup=3):
@@ -41,6 +41,28 @@ def main():
     prev = np.ascontiguousarray(np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32))
     dtm = timed(lambda: ctx.match_window(k1, d1, k2, d2, w, h, prev.copy(), 100, 0.9, True), 100)
     out["orb_match_window_1000x1000"] = {"wall_ms": round(dtm * 1e3, 4)}
+    # bag of words: a 10-ary vocabulary of depth 5 (111 110 nodes), transform at 4 levels up, SearchByBoW
+    voc = binding.Vocabulary.from_arrays(10, 5, 0, 0, *synth_vocabulary(10, 5, seed=1))
+    dtv = timed(lambda: voc.transform(d1, 4), 100)
+    _, fv1 = voc.transform(d1, 4)
+    _, fv2 = voc.transform(d2, 4)
+    valid = np.ones(len(k1), np.uint8)
+    dtb = timed(lambda: ctx.match_bow(k1, d1, valid, fv1, k2, d2, fv2, 0.7, True), 100)
+    out["orb_voc_bow_1000"] = {"wall_ms": round(dtv * 1e3, 4)}
+    out["orb_match_bow_1000x1000"] = {"wall_ms": round(dtb * 1e3, 4)}
+    import torch as _t
+    big = _t.randint(0, 256, (256 * 1000, 32), dtype=_t.uint8, device="cuda")
+    word = _t.zeros(256 * 1000, dtype=_t.int32, device="cuda")
+    node = _t.zeros_like(word)
+    wt = _t.zeros(256 * 1000, dtype=_t.float64, device="cuda")
+
+    def dev_step():
+        voc.transform_features_device(big, 4, word, wt, node)
+        _t.cuda.synchronize()
+
+    dtd = timed(dev_step, 20)
+    out["orb_voc_transform_device_256000"] = {"wall_ms": round(dtd * 1e3, 4), "descriptors_per_s": round(256000 / dtd, 0)}
+    voc.close()
     ctx.close()
     for batch in (64, 256):
         ctx = binding.Context(1000, 1.2, 8, 20, 7, w, h, batch, 0, binding.ORB_QUIRKS_FORK)
