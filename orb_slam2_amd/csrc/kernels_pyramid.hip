@@ -10,7 +10,7 @@
 
 #include "orb_internal.h"
 
-// Resize, both interpolation modes, separably.  One workgroup produces a 64x16 destination tile:
+// Resize, both interpolation modes, separably.  One workgroup produces a 64x32 destination tile:
 // the source rectangle its taps can touch (orb_resize_span, a superset checked against the tap
 // tables on the host) is fetched into LDS as whole dwords; a horizontal pass evaluates, for every
 // staged source row and every destination column, the row's contribution
@@ -21,7 +21,10 @@
 //   linear: (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2
 // four adjacent pixels per thread, stored as one dword.  This is the order cv::resize itself works in,
 // so sharing the horizontal results between destination rows changes nothing.
-template <bool AREA>
+typedef float float2v __attribute__((ext_vector_type(2)));  // element-wise products and sums: v_pk_mul_f32 / v_pk_add_f32
+
+// NT = taps per axis the area tables use at most (3 for any level ratio below 2, else ORB_MAX_TAPS).
+template <bool AREA, int NT>
 __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict__ src, int sw, int sh, int sstride,
                                                       int64_t sFrame, uint8_t* __restrict__ dst, int dw, int dh,
                                                       int dpitch, int64_t dFrame, const void* __restrict__ xtab,
@@ -86,15 +89,25 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
             const int sh = b0 & 3;
             const uint32_t* rowp = (const uint32_t*)tile + (b0 >> 2);
             const int rowStep = tp >> 2;
-            for (int r = q; r < nrows; r += 4) {
-                const uint32_t lo = rowp[r * rowStep], hi = rowp[r * rowStep + 1];
-                const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
-                float buf = 0.f;
-                buf = __fadd_rn(buf, __fmul_rn((float)(w & 255u), txa.a[0]));
-                buf = __fadd_rn(buf, __fmul_rn((float)((w >> 8) & 255u), txa.a[1]));
-                buf = __fadd_rn(buf, __fmul_rn((float)((w >> 16) & 255u), txa.a[2]));
-                buf = __fadd_rn(buf, __fmul_rn((float)(w >> 24), txa.a[3]));
-                bufF[r * ORB_RS_TW + dx] = buf;
+            // two staged rows at a time (the LDS regions hold one row more than any tile stages, so the
+            // partner of a last odd row exists); the first product needs no sum: 0 + x == x for x >= +0
+            for (int r = 2 * q; r < nrows; r += 8) {
+                const uint32_t* p0 = rowp + r * rowStep;
+                const uint32_t* p1 = p0 + rowStep;
+                const uint32_t w0 = __builtin_amdgcn_alignbyte(p0[1], p0[0], sh);
+                const uint32_t w1 = __builtin_amdgcn_alignbyte(p1[1], p1[0], sh);
+                float2v px = {(float)(w0 & 255u), (float)(w1 & 255u)};
+                float2v buf = px * txa.a[0];
+                px = float2v{(float)((w0 >> 8) & 255u), (float)((w1 >> 8) & 255u)};
+                buf = buf + px * txa.a[1];
+                px = float2v{(float)((w0 >> 16) & 255u), (float)((w1 >> 16) & 255u)};
+                buf = buf + px * txa.a[2];
+                if (NT > 3) {
+                    px = float2v{(float)(w0 >> 24), (float)(w1 >> 24)};
+                    buf = buf + px * txa.a[3];
+                }
+                bufF[r * ORB_RS_TW + dx] = buf.x;
+                bufF[(r + 1) * ORB_RS_TW + dx] = buf.y;
             }
         } else {
             for (int r = q; r < nrows; r += 4) {
@@ -104,47 +117,50 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
         }
     }
     __syncthreads();
-    // vertical pass: four adjacent columns of one destination row per thread
-    const int cg = t & 15, row = t >> 4;
-    const int x = x0 + 4 * cg, y = y0 + row;
-    if (x >= dw || y >= dh) return;
-    uint32_t outw = 0u;
-    if (AREA) {
-        const OrbAreaTap ty = s_ya[row];
-        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+    // vertical pass: four adjacent columns of one destination row per thread and round
+    const int cg = t & 15;
+    const int x = x0 + 4 * cg;
+    if (x >= dw) return;
 #pragma unroll
-        for (int j = 0; j < ORB_MAX_TAPS; j++) {
-            if (ty.a[j] == 0.f) break;
-            const float4 b = *(const float4*)&bufF[(ty.si[j] - sy0) * ORB_RS_TW + 4 * cg];
-            const float term[4] = {__fmul_rn(ty.a[j], b.x), __fmul_rn(ty.a[j], b.y), __fmul_rn(ty.a[j], b.z),
-                                   __fmul_rn(ty.a[j], b.w)};
+    for (int row = t >> 4; row < ORB_RS_TH; row += 16) {
+        const int y = y0 + row;
+        if (y >= dh) break;
+        uint32_t outw = 0u;
+        if (AREA) {
+            // all NT taps, no early exit: an unused tap has weight 0 and names the row of the last used one
+            const OrbAreaTap ty = s_ya[row];
+            float2v s01, s23;
 #pragma unroll
-            for (int i = 0; i < 4; i++) sum[i] = (j == 0) ? term[i] : __fadd_rn(sum[i], term[i]);
+            for (int j = 0; j < NT; j++) {
+                const float4 b = *(const float4*)&bufF[(ty.si[j] - sy0) * ORB_RS_TW + 4 * cg];
+                const float2v t01 = float2v{b.x, b.y} * ty.a[j], t23 = float2v{b.z, b.w} * ty.a[j];
+                s01 = (j == 0) ? t01 : s01 + t01;
+                s23 = (j == 0) ? t23 : s23 + t23;
+            }
+            // saturate_cast<uchar>: round half to even, clamp, one instruction per pixel
+            outw = __builtin_amdgcn_cvt_pk_u8_f32(s01.x, 0u, outw);
+            outw = __builtin_amdgcn_cvt_pk_u8_f32(s01.y, 1u, outw);
+            outw = __builtin_amdgcn_cvt_pk_u8_f32(s23.x, 2u, outw);
+            outw = __builtin_amdgcn_cvt_pk_u8_f32(s23.y, 3u, outw);
+        } else {
+            const OrbLinTap ty = s_yl[row];
+            const int4 h0 = *(const int4*)&bufI[(ty.s0 - sy0) * ORB_RS_TW + 4 * cg];
+            const int4 h1 = *(const int4*)&bufI[(ty.s1 - sy0) * ORB_RS_TW + 4 * cg];
+            const int H0[4] = {h0.x, h0.y, h0.z, h0.w}, H1[4] = {h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int v = (((ty.a0 * (H0[i] >> 4)) >> 16) + ((ty.a1 * (H1[i] >> 4)) >> 16) + 2) >> 2;
+                outw |= (uint32_t)(v & 255) << (8 * i);
+            }
         }
+        uint8_t* D = dst + (int64_t)blockIdx.z * dFrame + (int64_t)y * dpitch + x;
+        if (x + 3 < dw && (((unsigned long long)D) & 3ull) == 0) {
+            *(uint32_t*)D = outw;
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int v = (int)rintf(sum[i]);
-            v = v < 0 ? 0 : (v > 255 ? 255 : v);
-            outw |= (uint32_t)v << (8 * i);
+            for (int i = 0; i < 4; i++)
+                if (x + i < dw) D[i] = (uint8_t)(outw >> (8 * i));
         }
-    } else {
-        const OrbLinTap ty = s_yl[row];
-        const int4 h0 = *(const int4*)&bufI[(ty.s0 - sy0) * ORB_RS_TW + 4 * cg];
-        const int4 h1 = *(const int4*)&bufI[(ty.s1 - sy0) * ORB_RS_TW + 4 * cg];
-        const int H0[4] = {h0.x, h0.y, h0.z, h0.w}, H1[4] = {h1.x, h1.y, h1.z, h1.w};
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int v = (((ty.a0 * (H0[i] >> 4)) >> 16) + ((ty.a1 * (H1[i] >> 4)) >> 16) + 2) >> 2;
-            outw |= (uint32_t)(v & 255) << (8 * i);
-        }
-    }
-    uint8_t* D = dst + (int64_t)blockIdx.z * dFrame + (int64_t)y * dpitch + x;
-    if (x + 3 < dw && (((unsigned long long)D) & 3ull) == 0) {
-        *(uint32_t*)D = outw;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            if (x + i < dw) D[i] = (uint8_t)(outw >> (8 * i));
     }
 }
 
@@ -199,13 +215,14 @@ static int check_launch(const char* what) {
     return ORB_OK;
 }
 
-static int launch_resize(bool area, const uint8_t* src, int sw, int sh, int sstride, int64_t sFrame, uint8_t* dst, int dw,
+static int launch_resize(bool area, int ntaps, const uint8_t* src, int sw, int sh, int sstride, int64_t sFrame, uint8_t* dst, int dw,
                          int dh, int dpitch, int64_t dFrame, const void* xt, const void* yt, int nframes,
                          hipStream_t st) {
     const double scaleX = orb_resize_scale(sw, dw), scaleY = orb_resize_scale(sh, dh);
     int tp = 0, rows = 0;
     orb_resize_tile_extent(sw, dw, scaleX, ORB_RS_TW, true, &tp);
     orb_resize_tile_extent(sh, dh, scaleY, ORB_RS_TH, false, &rows);
+    rows += 1;  // the horizontal pass works on pairs of rows
     const size_t lds = ORB_RS_TAP_BYTES + (((size_t)tp * rows + 15) & ~(size_t)15) + (size_t)rows * ORB_RS_TW * 4;
     if (lds > 64 * 1024 || tp / 4 > 256) {  // (the kernel stages one tile row with at most 256 threads)
         orb_set_error("resize %dx%d -> %dx%d: source tile of %zu bytes does not fit the kernel's LDS budget", sw, sh, dw,
@@ -213,11 +230,14 @@ static int launch_resize(bool area, const uint8_t* src, int sw, int sh, int sstr
         return ORB_ERR_UNSUPPORTED;
     }
     dim3 grid((dw + ORB_RS_TW - 1) / ORB_RS_TW, (dh + ORB_RS_TH - 1) / ORB_RS_TH, nframes);
-    if (area)
-        hipLaunchKernelGGL(k_resize_tiled<true>, grid, dim3(256), lds, st, src, sw, sh, sstride, sFrame, dst, dw, dh,
+    if (area && ntaps <= 3)
+        hipLaunchKernelGGL((k_resize_tiled<true, 3>), grid, dim3(256), lds, st, src, sw, sh, sstride, sFrame, dst, dw, dh,
+                           dpitch, dFrame, xt, yt, scaleX, scaleY, tp, rows);
+    else if (area)
+        hipLaunchKernelGGL((k_resize_tiled<true, ORB_MAX_TAPS>), grid, dim3(256), lds, st, src, sw, sh, sstride, sFrame, dst, dw, dh,
                            dpitch, dFrame, xt, yt, scaleX, scaleY, tp, rows);
     else
-        hipLaunchKernelGGL(k_resize_tiled<false>, grid, dim3(256), lds, st, src, sw, sh, sstride, sFrame, dst, dw, dh,
+        hipLaunchKernelGGL((k_resize_tiled<false, 2>), grid, dim3(256), lds, st, src, sw, sh, sstride, sFrame, dst, dw, dh,
                            dpitch, dFrame, xt, yt, scaleX, scaleY, tp, rows);
     return check_launch("resize");
 }
@@ -234,7 +254,7 @@ int orb_launch_pyramid(const OrbBatch& b) {
         const int64_t sFrame = (l == 1) ? b.frameStride0 : P.frameStride;
         const void* xt = area ? (const void*)(b.d_areaTaps + D.tabX) : (const void*)(b.d_linTaps + D.tabX);
         const void* yt = area ? (const void*)(b.d_areaTaps + D.tabY) : (const void*)(b.d_linTaps + D.tabY);
-        int rc = launch_resize(area, src + b.frame0 * sFrame, P.w, P.h, sstride, sFrame,
+        int rc = launch_resize(area, g.areaTapsMax, src + b.frame0 * sFrame, P.w, P.h, sstride, sFrame,
                                b.d_pyr + D.off + b.frame0 * D.frameStride, D.w, D.h, D.pitch, D.frameStride, xt, yt,
                                b.nframes, st);
         if (rc) return rc;
@@ -245,7 +265,7 @@ int orb_launch_pyramid(const OrbBatch& b) {
 int orb_launch_resize_single(const uint8_t* d_src, int sw, int sh, int sstride, uint8_t* d_dst, int dw, int dh,
                              int dstride, const OrbAreaTap* d_ax, const OrbAreaTap* d_ay, const OrbLinTap* d_lx,
                              const OrbLinTap* d_ly, int area, void* stream) {
-    return launch_resize(area != 0, d_src, sw, sh, sstride, 0, d_dst, dw, dh, dstride, 0,
+    return launch_resize(area != 0, ORB_MAX_TAPS, d_src, sw, sh, sstride, 0, d_dst, dw, dh, dstride, 0,
                          area ? (const void*)d_ax : (const void*)d_lx, area ? (const void*)d_ay : (const void*)d_ly, 1,
                          (hipStream_t)stream);
 }

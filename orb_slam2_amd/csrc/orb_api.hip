@@ -245,6 +245,7 @@ static int area_taps(int ssize, int dsize, std::vector<OrbAreaTap>& out) {
             orb_set_error("scale factor too large: more than %d source cells per destination pixel", ORB_MAX_TAPS);
             return ORB_ERR_UNSUPPORTED;
         }
+        for (int j = k; j < ORB_MAX_TAPS; j++) t.si[j] = t.si[k - 1];  // unused taps: weight 0 on a cell that is staged anyway
         out.push_back(t);
     }
     return ORB_OK;
@@ -433,6 +434,10 @@ static int compute_geom(orb_ctx* c, int w, int h) {
     g.outCapFrame = outBase;
     g.keysPerFrame = keyBase;
     g.nodesPerFrame = nodeBase;
+    g.areaTapsMax = 1;
+    for (const OrbAreaTap& t : at)
+        for (int j = 1; j < ORB_MAX_TAPS; j++)
+            if (t.a[j] != 0.f) g.areaTapsMax = std::max(g.areaTapsMax, j + 1);
     c->geom = g;
     c->areaTaps.swap(at);
     c->linTaps.swap(lt);

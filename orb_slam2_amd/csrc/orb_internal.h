@@ -40,6 +40,7 @@ struct OrbGeom {
     int nlevels, w, h;
     int cellsPerFrame, cellCap;   // cellCap: key slots per cell
     int maxCellW, maxCellH;       // largest FAST cell interior over all levels
+    int areaTapsMax;              // most source cells any area-resize tap entry of the pyramid uses (per axis)
     int outCapFrame;              // sum of outCap
     int64_t keysPerFrame;         // sum of keyCap
     int64_t nodesPerFrame;        // sum of nodeCap
@@ -63,7 +64,7 @@ struct OrbLinTap {   // one destination index of the linear resize
 // linear taps in [floor(d0 * scale) - 1, floor(d1 * scale) + 2] once float rounding of the sample
 // position is allowed for.  The host checks the tap tables against it before the first launch.
 #define ORB_RS_TW 64
-#define ORB_RS_TH 16
+#define ORB_RS_TH 32
 #define ORB_RS_TAP_BYTES (ORB_RS_TH * 32)   // the tile's vertical taps, staged in LDS
 #ifdef __HIPCC__
 #define ORB_HD __host__ __device__
