@@ -19,7 +19,8 @@
 #define RAW_N 43
 #define RAW_P 48   // 12 dwords: a window row starting at any byte alignment fits
 #define HGROUPS 11 // 4-column groups of a 44-column aligned row
-#define HB_P 44    // 16-bit horizontal sums per row, at the aligned columns of the LDS row
+#define HB_P 44    // horizontal sums (16 bit) of a row pair per aligned column of the LDS row: one dword each
+#define HB_PAIRS 22  // row pairs (0,1) .. (42,43); row 43 does not exist, its sums meet weight 0 only
 #define BL_N 37
 #define BL_P 44
 
@@ -146,8 +147,8 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
                                                              orb_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                              int capPerFrame, int* __restrict__ nOut,
                                                              int* __restrict__ error) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_raw[DESC_WAVES][RAW_N * RAW_P];
-    __shared__ __attribute__((aligned(16))) uint16_t s_hb[DESC_WAVES][RAW_N * HB_P];
+    __shared__ __attribute__((aligned(16))) uint8_t s_raw[DESC_WAVES][(RAW_N + 1) * RAW_P];  // + the partner row of row 42
+    __shared__ __attribute__((aligned(16))) uint32_t s_hb[DESC_WAVES][HB_PAIRS * HB_P];
     // the wavefront index is the same in all 64 lanes: telling the compiler so keeps everything derived from
     // it (frame, level, keypoint, window addresses, loop bounds) in scalar registers
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
         pitch = L.pitch;
     }
     uint8_t* raw = s_raw[wave];
-    uint16_t* hb = s_hb[wave];
+    uint32_t* hb = s_hb[wave];
     uint8_t* bl = s_raw[wave];  // the blurred window (37 x 44 bytes) takes the place of the source window, which the
                                 // horizontal pass has consumed by the time the vertical pass writes it
 
@@ -261,66 +262,73 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
 
     // Blur of the 37x37 window the pattern can reach.  Both passes work on the aligned columns of the
     // LDS rows, four at a time from whole dwords: horizontal 8.8 sums (16 bit), then vertical with one
-    // rounding.  Aligned columns outside [off + 3, off + 39] hold sums of bytes that are not part of
+    // rounding (taps against pairs of rows with v_dot2_u32_u16).  Aligned columns outside [off + 3, off + 39] hold sums of bytes that are not part of
     // the window; nothing reads them.
     const bool legacy = (g->quirks & ORB_Q_GAUSS_LEGACY) != 0;
     const uint32_t k0 = 18, k1 = 34, k2 = legacy ? 49 : 48, k3 = legacy ? 55 : 56;
-    const uint32_t wA = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24);  // taps 0..3 against four consecutive bytes
-    const uint32_t wB = k2 | (k1 << 8) | (k0 << 16);               // taps 4..6
+    // taps k0 k1 k2 k3 k2 k1 k0 against the bytes of the dwords A (columns 4q-4..4q-1), B (4q..4q+3), C (4q+4..4q+7)
+    // for the outputs at columns 4q + 0..3
+    const uint32_t wA0 = (k0 << 8) | (k1 << 16) | (k2 << 24), wB0 = k3 | (k2 << 8) | (k1 << 16) | (k0 << 24);
+    const uint32_t wA1 = (k0 << 16) | (k1 << 24), wB1 = k2 | (k3 << 8) | (k2 << 16) | (k1 << 24), wC1 = k0;
+    const uint32_t wA2 = k0 << 24, wB2 = k1 | (k2 << 8) | (k3 << 16) | (k2 << 24), wC2 = k1 | (k0 << 8);
+    const uint32_t wB3 = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), wC3 = k2 | (k1 << 8) | (k0 << 16);
     const uint32_t* raw32 = (const uint32_t*)s_raw[wave];
     uint32_t* hb32 = (uint32_t*)hb;
-    // lane = (row within a pass of five, group of four columns); lanes 55..63 idle
+    // lane = (row pair within a pass of five, group of four columns); lanes 55..63 idle.  The horizontal
+    // sums of rows 2p and 2p + 1 are stored side by side, one dword per column: the vertical pass then
+    // takes its seven rows as four such dwords whatever the parity of its first row, with no shuffling.
     const int rr = lane / HGROUPS, q = lane - rr * HGROUPS;
     if (rr < 5) {
-        const uint32_t* p = raw32 + rr * (RAW_P / 4) + q;
-        uint32_t* dsth = hb32 + rr * (HB_P / 2) + 2 * q;
         const int back = q > 0 ? -1 : 0;
 #pragma unroll
-        for (int it = 0; it < 9; it++, p += 5 * (RAW_P / 4), dsth += 5 * (HB_P / 2)) {
-            if (rr + 5 * it < RAW_N) {
-                const uint32_t A = p[back], B = p[0], C = p[1];
-                // output m of the group sums bytes m-3 .. m+3 around column 4q + m: two unaligned dwords each
-                const uint32_t o0 = dot4_u8(__builtin_amdgcn_alignbyte(B, A, 1), wA, dot4_u8(__builtin_amdgcn_alignbyte(C, B, 1), wB, 0u));
-                const uint32_t o1 = dot4_u8(__builtin_amdgcn_alignbyte(B, A, 2), wA, dot4_u8(__builtin_amdgcn_alignbyte(C, B, 2), wB, 0u));
-                const uint32_t o2 = dot4_u8(__builtin_amdgcn_alignbyte(B, A, 3), wA, dot4_u8(__builtin_amdgcn_alignbyte(C, B, 3), wB, 0u));
-                const uint32_t o3 = dot4_u8(B, wA, dot4_u8(C, wB, 0u));
-                uint2 o;
-                o.x = (o0 & 0xffffu) | (o1 << 16);  // (sums stay below 2^16)
-                o.y = (o2 & 0xffffu) | (o3 << 16);
-                *(uint2*)dsth = o;
+        for (int it = 0; it < 5; it++) {
+            const int pr = rr + 5 * it;
+            if (pr < HB_PAIRS) {
+                const uint32_t* p = raw32 + 2 * pr * (RAW_P / 4) + q;
+                uint32_t o[2][4];
+#pragma unroll
+                for (int h = 0; h < 2; h++, p += RAW_P / 4) {
+                    const uint32_t A = p[back], B = p[0], C = p[1];
+                    // output m of the group sums bytes m-3 .. m+3 around column 4q + m: the seven taps laid over
+                    // the three aligned dwords that hold them (no byte alignment of the data)
+                    o[h][0] = dot4_u8(A, wA0, dot4_u8(B, wB0, 0u));
+                    o[h][1] = dot4_u8(A, wA1, dot4_u8(B, wB1, dot4_u8(C, wC1, 0u)));
+                    o[h][2] = dot4_u8(A, wA2, dot4_u8(B, wB2, dot4_u8(C, wC2, 0u)));
+                    o[h][3] = dot4_u8(B, wB3, dot4_u8(C, wC3, 0u));
+                }
+                uint4 e;  // (sums stay below 2^16)
+                e.x = (o[1][0] << 16) + o[0][0];
+                e.y = (o[1][1] << 16) + o[0][1];
+                e.z = (o[1][2] << 16) + o[0][2];
+                e.w = (o[1][3] << 16) + o[0][3];
+                *(uint4*)(hb32 + pr * HB_P + 4 * q) = e;
             }
         }
     }
     wave_lds_sync();
     uint32_t* bl32 = (uint32_t*)bl;
-    const uint32_t wP0 = k0 | (k1 << 16), wP1 = k2 | (k3 << 16), wP2 = k2 | (k1 << 16);  // row pairs (0,1) (2,3) (4,5)
+    // tap pairs against (row 2p, row 2p + 1) for an even first row r = 2p, and for an odd one r = 2p + 1
+    const uint32_t wE0 = k0 | (k1 << 16), wE1 = k2 | (k3 << 16), wE2 = k2 | (k1 << 16), wE3 = k0;
+    const uint32_t wO0 = k0 << 16, wO1 = k1 | (k2 << 16), wO2 = k3 | (k2 << 16), wO3 = k1 | (k0 << 16);
     if (rr < 5) {
 #pragma unroll 1
         for (int r = rr; r < BL_N; r += 5) {
-            const uint32_t* p = hb32 + r * (HB_P / 2) + 2 * q;
-            uint2 h[7];
-#pragma unroll
-            for (int i = 0; i < 7; i++) h[i] = *(const uint2*)(p + i * (HB_P / 2));
+            const bool odd = (r & 1) != 0;
+            const uint32_t w0 = odd ? wO0 : wE0, w1 = odd ? wO1 : wE1, w2 = odd ? wO2 : wE2, w3 = odd ? wO3 : wE3;
+            const uint32_t* p = hb32 + (r >> 1) * HB_P + 4 * q;
+            const uint4 e0 = *(const uint4*)p, e1 = *(const uint4*)(p + HB_P), e2 = *(const uint4*)(p + 2 * HB_P),
+                        e3 = *(const uint4*)(p + 3 * HB_P);
+            const uint32_t c0[4] = {e0.x, e0.y, e0.z, e0.w}, c1[4] = {e1.x, e1.y, e1.z, e1.w};
+            const uint32_t c2[4] = {e2.x, e2.y, e2.z, e2.w}, c3[4] = {e3.x, e3.y, e3.z, e3.w};
             uint32_t packed = 0;
 #pragma unroll
-            for (int half = 0; half < 2; half++) {  // dword `half` holds columns 2*half and 2*half + 1
-                uint32_t hw[7];
-#pragma unroll
-                for (int i = 0; i < 7; i++) hw[i] = half ? h[i].y : h[i].x;
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    // (row i, row i+1) of one column side by side; the seventh row is weighted inside its own dword
-                    const uint32_t sel = c ? 0x07060302u : 0x05040100u;
-                    const uint32_t p01 = __builtin_amdgcn_perm(hw[1], hw[0], sel);
-                    const uint32_t p23 = __builtin_amdgcn_perm(hw[3], hw[2], sel);
-                    const uint32_t p45 = __builtin_amdgcn_perm(hw[5], hw[4], sel);
-                    uint32_t v = dot2_u16(hw[6], c ? (k0 << 16) : k0, 32768u);
-                    v = dot2_u16(p45, wP2, v);
-                    v = dot2_u16(p23, wP1, v);
-                    v = dot2_u16(p01, wP0, v);
-                    v >>= 16;
-                    packed |= (v > 255u ? 255u : v) << (8 * (2 * half + c));
-                }
+            for (int c = 0; c < 4; c++) {
+                uint32_t v = dot2_u16(c0[c], w0, 32768u);
+                v = dot2_u16(c1[c], w1, v);
+                v = dot2_u16(c2[c], w2, v);
+                v = dot2_u16(c3[c], w3, v);
+                v >>= 16;
+                packed |= (v > 255u ? 255u : v) << (8 * c);
             }
             bl32[r * (BL_P / 4) + q] = packed;
         }
