@@ -104,6 +104,20 @@ static __device__ __forceinline__ void sincos_portable(float xf, float* s, float
     *c = (float)co;
 }
 
+// lane / D for lane in 0..63 with a 24-bit multiply (the general 32-bit division by a constant costs a
+// quarter-rate v_mul_hi_u32)
+template <int D>
+static constexpr bool lane_div_ok() {
+    for (int l = 0; l < 64; l++)
+        if (((l * (512 / D + 1)) >> 9) != l / D) return false;
+    return true;
+}
+template <int D>
+static __device__ __forceinline__ int lane_div(int lane) {
+    static_assert(lane_div_ok<D>(), "multiplier does not reproduce lane / D");
+    return (int)(__umul24((unsigned)lane, 512 / D + 1) >> 9);
+}
+
 static __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -204,15 +218,20 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
                           (((unsigned long long)img) & 3ull) == 0;
     const int off = fastLoad ? (wx0 - xa) : 0;
     if (fastLoad) {
-        // lane = (row within a group of five, dword); nine groups cover the 43 rows, all loads in flight at once
-        const int rr = lane / (RAW_P / 4), d = lane - rr * (RAW_P / 4);
+        // lane = (row within a group of five, dword); nine groups cover the 43 rows, all loads in flight at once.
+        // The window's origin is the same for all lanes (scalar 64-bit address), a lane adds a 32-bit offset.
+        const int rr = lane_div<RAW_P / 4>(lane), d = lane - rr * (RAW_P / 4);
         if (rr < 5) {
-            const uint8_t* src = img + (int64_t)(wy0 + rr) * pitch + xa + 4 * d;
+            // (the stride of five rows goes through a lane read so that it stays a plain addend: folded into
+            // the address it becomes one quarter-rate 64-bit multiply-add per row)
+            const int64_t step = (int64_t)__builtin_amdgcn_readfirstlane(5 * pitch);
+            const uint8_t* base = img + (int64_t)wy0 * pitch + xa +
+                                  (__umul24((unsigned)rr, (unsigned)pitch) + 4u * (unsigned)d);
             uint32_t* dstw = (uint32_t*)raw + rr * (RAW_P / 4) + d;
             uint32_t v[9];
 #pragma unroll
             for (int it = 0; it < 9; it++)
-                if (rr + 5 * it < RAW_N) v[it] = *(const uint32_t*)(src + (int64_t)(5 * it) * pitch);
+                if (rr + 5 * it < RAW_N) v[it] = *(const uint32_t*)(base + it * step);
 #pragma unroll
             for (int it = 0; it < 9; it++)
                 if (rr + 5 * it < RAW_N) dstw[it * 5 * (RAW_P / 4)] = v[it];
@@ -233,8 +252,15 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
         // rows v = -15..15, aligned column groups 1..9 (they cover u = -15..15 for every `off`)
         const uint32_t* raw32 = (const uint32_t*)s_raw[wave];
         // lane = (row within a pass of seven, dword group 1..9); five passes cover the 31 rows
-        const int rr = lane / 9, q = 1 + (lane - rr * 9);
+        const int rr = lane_div<9>(lane), q = 1 + (lane - rr * 9);
         const int u0 = 4 * q - off - 21;  // u of the dword's first byte
+        // byte weights u + 32 = u0 + 32 + i (positive for every dword a lane can hold), taken off again through
+        // the plain sum m00: sum u * I = sum (u + 32) * I - 32 * sum I
+        uint32_t wU = (uint32_t)(u0 + 32);
+        wU |= wU << 8;
+        wU |= wU << 16;
+        wU += 0x03020100u;
+        int m00 = 0;
         if (rr < 7) {
 #pragma unroll
             for (int it = 0; it < 5; it++) {
@@ -243,18 +269,17 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
                     const int v = r - 15, av = v < 0 ? -v : v;
                     const int lim = (int)((um >> (4 * av)) & 15ull);
                     const uint32_t w = raw32[(6 + r) * (RAW_P / 4) + q];
-                    // bytes lo..hi of the dword lie inside the patch row (|u| <= lim)
+                    // bytes lo..hi of the dword lie inside the patch row (|u| <= lim); none when lo > hi
                     const int lo = max(0, -lim - u0), hi = min(3, lim - u0);
-                    if (lo <= hi) {
-                        const uint32_t ones = (0x01010101u << (8 * lo)) & (0x01010101u >> (8 * (3 - hi)));
-                        const uint32_t idx = (ones * 0xffu) & 0x03020100u;
-                        const int rowSum = (int)dot4_u8(w, ones, 0u);
-                        m10 += u0 * rowSum + (int)dot4_u8(w, idx, 0u);
-                        m01 += v * rowSum;
-                    }
+                    const uint32_t in = lo <= hi ? (0xffffffffu << (8 * lo)) & (0xffffffffu >> (8 * (3 - hi))) : 0u;
+                    const int rowSum = (int)dot4_u8(w, in & 0x01010101u, 0u);
+                    m10 = (int)dot4_u8(w, in & wU, (uint32_t)m10);
+                    m00 += rowSum;
+                    m01 += __mul24(v, rowSum);
                 }
             }
         }
+        m10 -= 32 * m00;
     }
     m10 = wave_sum(m10);
     m01 = wave_sum(m01);
@@ -277,7 +302,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     // lane = (row pair within a pass of five, group of four columns); lanes 55..63 idle.  The horizontal
     // sums of rows 2p and 2p + 1 are stored side by side, one dword per column: the vertical pass then
     // takes its seven rows as four such dwords whatever the parity of its first row, with no shuffling.
-    const int rr = lane / HGROUPS, q = lane - rr * HGROUPS;
+    const int rr = lane_div<HGROUPS>(lane), q = lane - rr * HGROUPS;
     if (rr < 5) {
         const int back = q > 0 ? -1 : 0;
 #pragma unroll
@@ -315,7 +340,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
         for (int r = rr; r < BL_N; r += 5) {
             const bool odd = (r & 1) != 0;
             const uint32_t w0 = odd ? wO0 : wE0, w1 = odd ? wO1 : wE1, w2 = odd ? wO2 : wE2, w3 = odd ? wO3 : wE3;
-            const uint32_t* p = hb32 + (r >> 1) * HB_P + 4 * q;
+            const uint32_t* p = hb32 + __umul24((unsigned)(r >> 1), HB_P) + 4 * q;
             const uint4 e0 = *(const uint4*)p, e1 = *(const uint4*)(p + HB_P), e2 = *(const uint4*)(p + 2 * HB_P),
                         e3 = *(const uint4*)(p + 3 * HB_P);
             const uint32_t c0[4] = {e0.x, e0.y, e0.z, e0.w}, c1[4] = {e1.x, e1.y, e1.z, e1.w};
@@ -350,8 +375,8 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
         const int dx0 = (int)rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
         const int dy1 = (int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
         const int dx1 = (int)rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = bl[(18 + dy0) * BL_P + 18 + dx0];
-        const int t1 = bl[(18 + dy1) * BL_P + 18 + dx1];
+        const int t0 = bl[__mul24(18 + dy0, BL_P) + 18 + dx0];
+        const int t1 = bl[__mul24(18 + dy1, BL_P) + 18 + dx1];
         words[r] = __ballot(t0 < t1);
     }
     if (lane == 0) {
