@@ -166,6 +166,22 @@ def test_extract_batch_equals_single(hip, oracle):
     c.close()
 
 
+def test_extract_batch_threaded_staging(hip, oracle):
+    """Batches of eight frames or more are staged by several host threads, each handing slices to the DMA
+    engine; strided rows take the row-by-row copy.  Every frame must come out as from a single call."""
+    n, w, h = 19, 320, 240
+    c = _ctx(hip, "fork", 500, 6, w, h, batch=n)
+    e = oracle.Extractor(500, 1.2, 6, 20, 7, PRESETS["fork"])
+    wide = np.stack([synth_scene(w + 24, h, frame_seed(2, 50 + f)) for f in range(n)])
+    imgs = [wide[f][:, 7 : 7 + w] for f in range(n)]  # views: contiguous copies are made by the binding
+    res = c.extract_batch(imgs)
+    for f in range(n):
+        ko, do = e.extract(np.ascontiguousarray(imgs[f]))
+        assert_kps_equal(res[f][0], ko, "frame %d" % f)
+        np.testing.assert_array_equal(res[f][1], do)
+    c.close()
+
+
 def test_extract_after_sparse_frames(hip, oracle):
     """The quadtree kernel sizes its LDS block from the key counts of earlier batches; a frame with
     far more keys than any before must come out the same (its levels run from global memory)."""
