@@ -23,104 +23,68 @@
 // so sharing the horizontal results between destination rows changes nothing.
 typedef float float2v __attribute__((ext_vector_type(2)));  // element-wise products and sums: v_pk_mul_f32 / v_pk_add_f32
 
-// NT = taps per axis the area tables use at most (3 for any level ratio below 2, else ORB_MAX_TAPS).
+#define RS_STAGE_REGS 6  // dwords of a source tile one thread can hold while the previous tile is worked on
+
+// Everything about one workgroup's column of tiles that does not change from tile to tile.
+struct RsTileCtx {
+    uint8_t* tile;   // staged source rows, tp bytes each
+    float* bufF;     // horizontal results, [rows][ORB_RS_TW]
+    int tp, sxa;     // LDS row pitch, first staged source column (multiple of 4)
+    int dx, q;       // column of this thread in the horizontal pass, wavefront index
+    bool colValid;
+};
+
+// Horizontal pass: column dx of every staged row.
 template <bool AREA, int NT>
-__global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict__ src, int sw, int sh, int sstride,
-                                                      int64_t sFrame, uint8_t* __restrict__ dst, int dw, int dh,
-                                                      int dpitch, int64_t dFrame, const void* __restrict__ xtab,
-                                                      const void* __restrict__ ytab, double scaleX, double scaleY,
-                                                      int tp, int rowsMax) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
-    OrbAreaTap* s_ya = (OrbAreaTap*)s_mem;
-    OrbLinTap* s_yl = (OrbLinTap*)s_mem;
-    uint8_t* tile = s_mem + ORB_RS_TAP_BYTES;
-    float* bufF = (float*)(tile + (((size_t)tp * rowsMax + 15) & ~(size_t)15));  // [rowsMax][ORB_RS_TW]
-    int* bufI = (int*)bufF;
-    const int t = threadIdx.x;
-    const int x0 = blockIdx.x * ORB_RS_TW, y0 = blockIdx.y * ORB_RS_TH;
-    const int x1 = min(x0 + ORB_RS_TW, dw), y1 = min(y0 + ORB_RS_TH, dh);
-    const int dx = t & 63, q = __builtin_amdgcn_readfirstlane(t >> 6);  // wavefront index: uniform
-    const bool colValid = x0 + dx < dw;
-    OrbAreaTap txa = {};
-    OrbLinTap txl = {};
-    if (colValid) {
-        if (AREA) txa = ((const OrbAreaTap*)xtab)[x0 + dx];
-        else txl = ((const OrbLinTap*)xtab)[x0 + dx];
-    }
-    if (t < ORB_RS_TH && y0 + t < dh) {
-        if (AREA) s_ya[t] = ((const OrbAreaTap*)ytab)[y0 + t];
-        else s_yl[t] = ((const OrbLinTap*)ytab)[y0 + t];
-    }
-    int sx0, sx1, sy0, sy1;
-    orb_resize_span(x0, x1, scaleX, sw, &sx0, &sx1);
-    orb_resize_span(y0, y1, scaleY, sh, &sy0, &sy1);
-    const int sxa = sx0 & ~3;
-    const int nd = (sx1 - sxa + 4) >> 2, nrows = sy1 - sy0 + 1;
-    const uint8_t* S = src + (int64_t)blockIdx.z * sFrame;
-    const bool aligned = (sstride & 3) == 0 && (((unsigned long long)S) & 3ull) == 0;
-    {   // thread = (row within a pass, dword); a pass covers 256 / nd rows
-        const int rpp = 256 / nd;  // nd <= 256: checked by the launcher
-        const int rr = t / nd, d = t - rr * nd;
-        const int col = sxa + 4 * d;
-        if (rr < rpp) {
-            for (int r = rr; r < nrows; r += rpp) {
-                const uint8_t* p = S + (int64_t)(sy0 + r) * sstride + col;
-                uint32_t v;
-                if (aligned && col + 3 < sw) {
-                    v = *(const uint32_t*)p;
-                } else {
-                    v = 0u;
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        if (col + i < sw) v |= (uint32_t)p[i] << (8 * i);
-                }
-                *(uint32_t*)&tile[r * tp + 4 * d] = v;
+static __device__ __forceinline__ void rs_horizontal(const RsTileCtx& c, const OrbAreaTap& txa, const OrbLinTap& txl,
+                                                     int nrows) {
+    if (!c.colValid) return;
+    if (AREA) {
+        // The taps of a column are consecutive source pixels starting at si[0]: fetch the two aligned dwords
+        // that hold them, shift the first tap to byte 0, and always take NT (unused taps have weight 0,
+        // and buf + pixel * 0 == buf exactly; what lies under them is some byte of the LDS allocation).
+        const int b0 = txa.si[0] - c.sxa;
+        const int sh = b0 & 3;
+        const uint32_t* rowp = (const uint32_t*)c.tile + (b0 >> 2);
+        const int rowStep = c.tp >> 2;
+        // two staged rows at a time (the LDS regions hold one row more than any tile stages, so the
+        // partner of a last odd row exists); the first product needs no sum: 0 + x == x for x >= +0
+        for (int r = 2 * c.q; r < nrows; r += 8) {
+            const uint32_t* p0 = rowp + r * rowStep;
+            const uint32_t* p1 = p0 + rowStep;
+            const uint32_t w0 = __builtin_amdgcn_alignbyte(p0[1], p0[0], sh);
+            const uint32_t w1 = __builtin_amdgcn_alignbyte(p1[1], p1[0], sh);
+            float2v px = {(float)(w0 & 255u), (float)(w1 & 255u)};
+            float2v buf = px * txa.a[0];
+            px = float2v{(float)((w0 >> 8) & 255u), (float)((w1 >> 8) & 255u)};
+            buf = buf + px * txa.a[1];
+            px = float2v{(float)((w0 >> 16) & 255u), (float)((w1 >> 16) & 255u)};
+            buf = buf + px * txa.a[2];
+            if (NT > 3) {
+                px = float2v{(float)(w0 >> 24), (float)(w1 >> 24)};
+                buf = buf + px * txa.a[3];
             }
+            c.bufF[r * ORB_RS_TW + c.dx] = buf.x;
+            c.bufF[(r + 1) * ORB_RS_TW + c.dx] = buf.y;
+        }
+    } else {
+        int* bufI = (int*)c.bufF;
+        for (int r = c.q; r < nrows; r += 4) {
+            const uint8_t* rowp = c.tile + r * c.tp - c.sxa;  // rowp[sx] is source pixel (sx, sy0 + r)
+            bufI[r * ORB_RS_TW + c.dx] = rowp[txl.s0] * txl.a0 + rowp[txl.s1] * txl.a1;
         }
     }
-    __syncthreads();
-    // horizontal pass: column dx of every staged row (wave q takes rows q, q + 4, ...)
-    if (colValid) {
-        if (AREA) {
-            // The taps of a column are consecutive source pixels starting at si[0]: fetch the two aligned dwords
-            // that hold them, shift the first tap to byte 0, and always take four (unused taps have weight 0,
-            // and buf + pixel * 0 == buf exactly; what lies under them is some byte of the LDS allocation).
-            const int b0 = txa.si[0] - sxa;
-            const int sh = b0 & 3;
-            const uint32_t* rowp = (const uint32_t*)tile + (b0 >> 2);
-            const int rowStep = tp >> 2;
-            // two staged rows at a time (the LDS regions hold one row more than any tile stages, so the
-            // partner of a last odd row exists); the first product needs no sum: 0 + x == x for x >= +0
-            for (int r = 2 * q; r < nrows; r += 8) {
-                const uint32_t* p0 = rowp + r * rowStep;
-                const uint32_t* p1 = p0 + rowStep;
-                const uint32_t w0 = __builtin_amdgcn_alignbyte(p0[1], p0[0], sh);
-                const uint32_t w1 = __builtin_amdgcn_alignbyte(p1[1], p1[0], sh);
-                float2v px = {(float)(w0 & 255u), (float)(w1 & 255u)};
-                float2v buf = px * txa.a[0];
-                px = float2v{(float)((w0 >> 8) & 255u), (float)((w1 >> 8) & 255u)};
-                buf = buf + px * txa.a[1];
-                px = float2v{(float)((w0 >> 16) & 255u), (float)((w1 >> 16) & 255u)};
-                buf = buf + px * txa.a[2];
-                if (NT > 3) {
-                    px = float2v{(float)(w0 >> 24), (float)(w1 >> 24)};
-                    buf = buf + px * txa.a[3];
-                }
-                bufF[r * ORB_RS_TW + dx] = buf.x;
-                bufF[(r + 1) * ORB_RS_TW + dx] = buf.y;
-            }
-        } else {
-            for (int r = q; r < nrows; r += 4) {
-                const uint8_t* rowp = tile + r * tp - sxa;  // rowp[sx] is source pixel (sx, sy0 + r)
-                bufI[r * ORB_RS_TW + dx] = rowp[txl.s0] * txl.a0 + rowp[txl.s1] * txl.a1;
-            }
-        }
-    }
-    __syncthreads();
-    // vertical pass: four adjacent columns of one destination row per thread and round
+}
+
+// Vertical pass: four adjacent columns of one destination row per thread and round; the tile's vertical taps
+// are in LDS at `taps`.
+template <bool AREA, int NT>
+static __device__ __forceinline__ void rs_vertical(const RsTileCtx& c, const void* taps, int t, int x0, int y0, int sy0,
+                                                   uint8_t* __restrict__ dstFrame, int dw, int dh, int dpitch) {
     const int cg = t & 15;
     const int x = x0 + 4 * cg;
     if (x >= dw) return;
+    const int* bufI = (const int*)c.bufF;
 #pragma unroll
     for (int row = t >> 4; row < ORB_RS_TH; row += 16) {
         const int y = y0 + row;
@@ -128,11 +92,11 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
         uint32_t outw = 0u;
         if (AREA) {
             // all NT taps, no early exit: an unused tap has weight 0 and names the row of the last used one
-            const OrbAreaTap ty = s_ya[row];
+            const OrbAreaTap ty = ((const OrbAreaTap*)taps)[row];
             float2v s01, s23;
 #pragma unroll
             for (int j = 0; j < NT; j++) {
-                const float4 b = *(const float4*)&bufF[(ty.si[j] - sy0) * ORB_RS_TW + 4 * cg];
+                const float4 b = *(const float4*)&c.bufF[(ty.si[j] - sy0) * ORB_RS_TW + 4 * cg];
                 const float2v t01 = float2v{b.x, b.y} * ty.a[j], t23 = float2v{b.z, b.w} * ty.a[j];
                 s01 = (j == 0) ? t01 : s01 + t01;
                 s23 = (j == 0) ? t23 : s23 + t23;
@@ -143,7 +107,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
             outw = __builtin_amdgcn_cvt_pk_u8_f32(s23.x, 2u, outw);
             outw = __builtin_amdgcn_cvt_pk_u8_f32(s23.y, 3u, outw);
         } else {
-            const OrbLinTap ty = s_yl[row];
+            const OrbLinTap ty = ((const OrbLinTap*)taps)[row];
             const int4 h0 = *(const int4*)&bufI[(ty.s0 - sy0) * ORB_RS_TW + 4 * cg];
             const int4 h1 = *(const int4*)&bufI[(ty.s1 - sy0) * ORB_RS_TW + 4 * cg];
             const int H0[4] = {h0.x, h0.y, h0.z, h0.w}, H1[4] = {h1.x, h1.y, h1.z, h1.w};
@@ -153,7 +117,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
                 outw |= (uint32_t)(v & 255) << (8 * i);
             }
         }
-        uint8_t* D = dst + (int64_t)blockIdx.z * dFrame + (int64_t)y * dpitch + x;
+        uint8_t* D = dstFrame + (int64_t)y * dpitch + x;
         if (x + 3 < dw && (((unsigned long long)D) & 3ull) == 0) {
             *(uint32_t*)D = outw;
         } else {
@@ -161,6 +125,120 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
             for (int i = 0; i < 4; i++)
                 if (x + i < dw) D[i] = (uint8_t)(outw >> (8 * i));
         }
+    }
+}
+
+// NT = taps per axis the area tables use at most (3 for any level ratio below 2, else ORB_MAX_TAPS).
+// PAIR: the workgroup makes two vertically adjacent tiles and fetches the source rows of the second into
+// registers while it works on the first (a wavefront otherwise spends most of its life waiting for its
+// tile); needs a tile to be at most RS_STAGE_REGS dwords per thread, which the launcher checks.
+template <bool AREA, int NT, bool PAIR>
+__global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict__ src, int sw, int sh, int sstride,
+                                                      int64_t sFrame, uint8_t* __restrict__ dst, int dw, int dh,
+                                                      int dpitch, int64_t dFrame, const void* __restrict__ xtab,
+                                                      const void* __restrict__ ytab, double scaleX, double scaleY,
+                                                      int tp, int rowsMax) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
+    const int t = threadIdx.x;
+    RsTileCtx c;
+    c.tile = s_mem + ORB_RS_TAP_BYTES;
+    c.bufF = (float*)(c.tile + (((size_t)tp * rowsMax + 15) & ~(size_t)15));  // [rowsMax][ORB_RS_TW]
+    c.tp = tp;
+    c.dx = t & 63;
+    c.q = __builtin_amdgcn_readfirstlane(t >> 6);  // wavefront index: uniform
+    const int x0 = blockIdx.x * ORB_RS_TW, x1 = min(x0 + ORB_RS_TW, dw);
+    c.colValid = x0 + c.dx < dw;
+    OrbAreaTap txa = {};
+    OrbLinTap txl = {};
+    if (c.colValid) {
+        if (AREA) txa = ((const OrbAreaTap*)xtab)[x0 + c.dx];
+        else txl = ((const OrbLinTap*)xtab)[x0 + c.dx];
+    }
+    int sx0, sx1;
+    orb_resize_span(x0, x1, scaleX, sw, &sx0, &sx1);
+    c.sxa = sx0 & ~3;
+    const int nd = (sx1 - c.sxa + 4) >> 2;
+    const uint8_t* S = src + (int64_t)blockIdx.z * sFrame;
+    uint8_t* D = dst + (int64_t)blockIdx.z * dFrame;
+    const bool aligned = (sstride & 3) == 0 && (((unsigned long long)S) & 3ull) == 0;
+    // staging: thread = (row within a pass, dword); a pass covers 256 / nd rows (nd <= 256: checked by the launcher)
+    const int rpp = 256 / nd;
+    const int rr = t / nd, d = t - rr * nd;
+    const int col = c.sxa + 4 * d;
+    const bool stager = rr < rpp;
+    auto fetch = [&](int sy0, int r) -> uint32_t {
+        const uint8_t* p = S + (int64_t)(sy0 + r) * sstride + col;
+        if (aligned && col + 3 < sw) return *(const uint32_t*)p;
+        uint32_t v = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (col + i < sw) v |= (uint32_t)p[i] << (8 * i);
+        return v;
+    };
+    auto stage_taps = [&](int y0) {
+        if (t < ORB_RS_TH && y0 + t < dh) {
+            if (AREA) ((OrbAreaTap*)s_mem)[t] = ((const OrbAreaTap*)ytab)[y0 + t];
+            else ((OrbLinTap*)s_mem)[t] = ((const OrbLinTap*)ytab)[y0 + t];
+        }
+    };
+    auto rows_of = [&](int y0, int* sy0, int* nrows) {
+        int s0, s1;
+        orb_resize_span(y0, min(y0 + ORB_RS_TH, dh), scaleY, sh, &s0, &s1);
+        *sy0 = s0;
+        *nrows = s1 - s0 + 1;
+    };
+
+    if (!PAIR) {
+        const int y0 = blockIdx.y * ORB_RS_TH;
+        int sy0, nrows;
+        rows_of(y0, &sy0, &nrows);
+        stage_taps(y0);
+        if (stager)
+            for (int r = rr; r < nrows; r += rpp) *(uint32_t*)&c.tile[r * tp + 4 * d] = fetch(sy0, r);
+        __syncthreads();
+        rs_horizontal<AREA, NT>(c, txa, txl, nrows);
+        __syncthreads();
+        rs_vertical<AREA, NT>(c, s_mem, t, x0, y0, sy0, D, dw, dh, dpitch);
+        return;
+    }
+
+    int y0 = blockIdx.y * (2 * ORB_RS_TH);
+    int sy0, nrows;
+    rows_of(y0, &sy0, &nrows);
+    uint32_t held[RS_STAGE_REGS];
+#pragma unroll
+    for (int k = 0; k < RS_STAGE_REGS; k++) {
+        const int r = rr + k * rpp;
+        held[k] = (stager && r < nrows) ? fetch(sy0, r) : 0u;
+    }
+    for (int s = 0; s < 2; s++) {
+#pragma unroll
+        for (int k = 0; k < RS_STAGE_REGS; k++) {
+            const int r = rr + k * rpp;
+            if (stager && r < nrows) *(uint32_t*)&c.tile[r * tp + 4 * d] = held[k];
+        }
+        stage_taps(y0);
+        __syncthreads();
+        // the second tile's rows are requested now and awaited after the first tile is done
+        const int ny0 = y0 + ORB_RS_TH;
+        const bool more = s == 0 && ny0 < dh;
+        int nsy0 = 0, nnrows = 0;
+        if (more) {
+            rows_of(ny0, &nsy0, &nnrows);
+#pragma unroll
+            for (int k = 0; k < RS_STAGE_REGS; k++) {
+                const int r = rr + k * rpp;
+                held[k] = (stager && r < nnrows) ? fetch(nsy0, r) : 0u;
+            }
+        }
+        rs_horizontal<AREA, NT>(c, txa, txl, nrows);
+        __syncthreads();
+        rs_vertical<AREA, NT>(c, s_mem, t, x0, y0, sy0, D, dw, dh, dpitch);
+        if (!more) break;
+        __syncthreads();  // tile, horizontal results and taps are free again
+        y0 = ny0;
+        sy0 = nsy0;
+        nrows = nnrows;
     }
 }
 
@@ -229,16 +307,22 @@ static int launch_resize(bool area, int ntaps, const uint8_t* src, int sw, int s
                       dh, lds);
         return ORB_ERR_UNSUPPORTED;
     }
-    dim3 grid((dw + ORB_RS_TW - 1) / ORB_RS_TW, (dh + ORB_RS_TH - 1) / ORB_RS_TH, nframes);
-    if (area && ntaps <= 3)
-        hipLaunchKernelGGL((k_resize_tiled<true, 3>), grid, dim3(256), lds, st, src, sw, sh, sstride, sFrame, dst, dw, dh,
-                           dpitch, dFrame, xt, yt, scaleX, scaleY, tp, rows);
-    else if (area)
-        hipLaunchKernelGGL((k_resize_tiled<true, ORB_MAX_TAPS>), grid, dim3(256), lds, st, src, sw, sh, sstride, sFrame, dst, dw, dh,
-                           dpitch, dFrame, xt, yt, scaleX, scaleY, tp, rows);
-    else
-        hipLaunchKernelGGL((k_resize_tiled<false, 2>), grid, dim3(256), lds, st, src, sw, sh, sstride, sFrame, dst, dw, dh,
-                           dpitch, dFrame, xt, yt, scaleX, scaleY, tp, rows);
+    const int tilesY = (dh + ORB_RS_TH - 1) / ORB_RS_TH;
+    // two tiles per workgroup when one tile is at most RS_STAGE_REGS dwords per thread (any level ratio up to ~1.5)
+    const int rowsPerPass = 256 / (tp / 4);
+    const bool pair = (rows + rowsPerPass - 1) / rowsPerPass <= RS_STAGE_REGS && tilesY > 1;
+    dim3 grid((dw + ORB_RS_TW - 1) / ORB_RS_TW, pair ? (tilesY + 1) / 2 : tilesY, nframes);
+#define RS_LAUNCH(AREA_, NT_, PAIR_)                                                                                  \
+    hipLaunchKernelGGL((k_resize_tiled<AREA_, NT_, PAIR_>), grid, dim3(256), lds, st, src, sw, sh, sstride, sFrame, dst, \
+                       dw, dh, dpitch, dFrame, xt, yt, scaleX, scaleY, tp, rows)
+    if (area && ntaps <= 3) {
+        if (pair) RS_LAUNCH(true, 3, true); else RS_LAUNCH(true, 3, false);
+    } else if (area) {
+        if (pair) RS_LAUNCH(true, ORB_MAX_TAPS, true); else RS_LAUNCH(true, ORB_MAX_TAPS, false);
+    } else {
+        if (pair) RS_LAUNCH(false, 2, true); else RS_LAUNCH(false, 2, false);
+    }
+#undef RS_LAUNCH
     return check_launch("resize");
 }
 
