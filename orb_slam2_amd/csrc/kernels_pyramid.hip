@@ -23,6 +23,7 @@
 // so sharing the horizontal results between destination rows changes nothing.
 typedef float float2v __attribute__((ext_vector_type(2)));  // element-wise products and sums: v_pk_mul_f32 / v_pk_add_f32
 
+#define RS_TILES_PER_WG 2  // vertically adjacent tiles one workgroup makes in turn (PAIR instances)
 #define RS_STAGE_REGS 6  // dwords of a source tile one thread can hold while the previous tile is worked on
 
 // Everything about one workgroup's column of tiles that does not change from tile to tile.
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
         return;
     }
 
-    int y0 = blockIdx.y * (2 * ORB_RS_TH);
+    int y0 = blockIdx.y * (RS_TILES_PER_WG * ORB_RS_TH);
     int sy0, nrows;
     rows_of(y0, &sy0, &nrows);
     uint32_t held[RS_STAGE_REGS];
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
         const int r = rr + k * rpp;
         held[k] = (stager && r < nrows) ? fetch(sy0, r) : 0u;
     }
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < RS_TILES_PER_WG; s++) {
 #pragma unroll
         for (int k = 0; k < RS_STAGE_REGS; k++) {
             const int r = rr + k * rpp;
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
         __syncthreads();
         // the second tile's rows are requested now and awaited after the first tile is done
         const int ny0 = y0 + ORB_RS_TH;
-        const bool more = s == 0 && ny0 < dh;
+        const bool more = s + 1 < RS_TILES_PER_WG && ny0 < dh;
         int nsy0 = 0, nnrows = 0;
         if (more) {
             rows_of(ny0, &nsy0, &nnrows);
@@ -311,7 +312,7 @@ static int launch_resize(bool area, int ntaps, const uint8_t* src, int sw, int s
     // two tiles per workgroup when one tile is at most RS_STAGE_REGS dwords per thread (any level ratio up to ~1.5)
     const int rowsPerPass = 256 / (tp / 4);
     const bool pair = (rows + rowsPerPass - 1) / rowsPerPass <= RS_STAGE_REGS && tilesY > 1;
-    dim3 grid((dw + ORB_RS_TW - 1) / ORB_RS_TW, pair ? (tilesY + 1) / 2 : tilesY, nframes);
+    dim3 grid((dw + ORB_RS_TW - 1) / ORB_RS_TW, pair ? (tilesY + RS_TILES_PER_WG - 1) / RS_TILES_PER_WG : tilesY, nframes);
 #define RS_LAUNCH(AREA_, NT_, PAIR_)                                                                                  \
     hipLaunchKernelGGL((k_resize_tiled<AREA_, NT_, PAIR_>), grid, dim3(256), lds, st, src, sw, sh, sstride, sFrame, dst, \
                        dw, dh, dpitch, dFrame, xt, yt, scaleX, scaleY, tp, rows)
