@@ -15,7 +15,7 @@
 
 #include "orb_internal.h"
 
-#define DESC_WAVES 4
+#define DESC_WAVES 1
 #define RAW_N 43
 #define RAW_P 48   // 12 dwords: a window row starting at any byte alignment fits
 #define HGROUPS 11 // 4-column groups of a 44-column aligned row
