@@ -18,8 +18,9 @@
 #define DESC_WAVES 1
 #define RAW_N 43
 #define RAW_P 48   // 12 dwords: a window row starting at any byte alignment fits
-#define HGROUPS 11 // 4-column groups of a 44-column aligned row
-#define HB_P 44    // horizontal sums (16 bit) of a row pair per aligned column of the LDS row: one dword each
+#define HGROUPS 10 // 4-column groups that hold the 37 blurred columns off+3 .. off+39, from group (off+3)/4 on
+#define HROWS 6    // rows (or row pairs) the 64 lanes take per pass: lane = (row, group), lanes 60..63 idle
+#define HB_P 40    // horizontal sums (16 bit) of a row pair per column of those groups: one dword each
 #define HB_PAIRS 22  // row pairs (0,1) .. (42,43); row 43 does not exist, its sums meet weight 0 only
 #define BL_N 37
 #define BL_P 44
@@ -299,15 +300,16 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     const uint32_t wB3 = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), wC3 = k2 | (k1 << 8) | (k0 << 16);
     const uint32_t* raw32 = (const uint32_t*)s_raw[wave];
     uint32_t* hb32 = (uint32_t*)hb;
-    // lane = (row pair within a pass of five, group of four columns); lanes 55..63 idle.  The horizontal
+    // lane = (row pair within a pass of six, group of four columns); lanes 60..63 idle.  The horizontal
     // sums of rows 2p and 2p + 1 are stored side by side, one dword per column: the vertical pass then
     // takes its seven rows as four such dwords whatever the parity of its first row, with no shuffling.
-    const int rr = lane_div<HGROUPS>(lane), q = lane - rr * HGROUPS;
-    if (rr < 5) {
+    const int rr = lane_div<HGROUPS>(lane), qi = lane - rr * HGROUPS;
+    const int q = ((off + 3) >> 2) + qi;  // the group's place in the LDS rows of the source and blurred windows
+    if (rr < HROWS) {
         const int back = q > 0 ? -1 : 0;
 #pragma unroll
-        for (int it = 0; it < 5; it++) {
-            const int pr = rr + 5 * it;
+        for (int it = 0; it < (HB_PAIRS + HROWS - 1) / HROWS; it++) {
+            const int pr = rr + HROWS * it;
             if (pr < HB_PAIRS) {
                 const uint32_t* p = raw32 + 2 * pr * (RAW_P / 4) + q;
                 uint32_t o[2][4];
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
                 e.y = (o[1][1] << 16) + o[0][1];
                 e.z = (o[1][2] << 16) + o[0][2];
                 e.w = (o[1][3] << 16) + o[0][3];
-                *(uint4*)(hb32 + pr * HB_P + 4 * q) = e;
+                *(uint4*)(hb32 + pr * HB_P + 4 * qi) = e;
             }
         }
     }
@@ -335,12 +337,12 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     // tap pairs against (row 2p, row 2p + 1) for an even first row r = 2p, and for an odd one r = 2p + 1
     const uint32_t wE0 = k0 | (k1 << 16), wE1 = k2 | (k3 << 16), wE2 = k2 | (k1 << 16), wE3 = k0;
     const uint32_t wO0 = k0 << 16, wO1 = k1 | (k2 << 16), wO2 = k3 | (k2 << 16), wO3 = k1 | (k0 << 16);
-    if (rr < 5) {
+    if (rr < HROWS) {
 #pragma unroll 1
-        for (int r = rr; r < BL_N; r += 5) {
+        for (int r = rr; r < BL_N; r += HROWS) {
             const bool odd = (r & 1) != 0;
             const uint32_t w0 = odd ? wO0 : wE0, w1 = odd ? wO1 : wE1, w2 = odd ? wO2 : wE2, w3 = odd ? wO3 : wE3;
-            const uint32_t* p = hb32 + __umul24((unsigned)(r >> 1), HB_P) + 4 * q;
+            const uint32_t* p = hb32 + __umul24((unsigned)(r >> 1), HB_P) + 4 * qi;
             const uint4 e0 = *(const uint4*)p, e1 = *(const uint4*)(p + HB_P), e2 = *(const uint4*)(p + 2 * HB_P),
                         e3 = *(const uint4*)(p + 3 * HB_P);
             const uint32_t c0[4] = {e0.x, e0.y, e0.z, e0.w}, c1[4] = {e1.x, e1.y, e1.z, e1.w};
