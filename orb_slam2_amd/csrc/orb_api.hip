@@ -112,7 +112,7 @@ struct orb_ctx {
     // levels) run under the throughput-bound stages of another.
     hipStream_t aux[ORB_MAX_PARTS - 1] = {};
     hipEvent_t evFork = nullptr, evJoin[ORB_MAX_PARTS - 1] = {};
-    int parts = 3;
+    int parts = 2;
     DevBuf dGeom, dAreaTaps, dLinTaps, dInput, dPyr, dCellKeys, dCellCount, dSort, dNodes, dInts,
         dSelXY, dSelScore, dLevelCount, dLevelKeys, dError, dKps, dDesc, dNOut, dTmpA, dTmpB;
     PinBuf pinIn, pinOut;  // host-pointer entry points only, sized on first use

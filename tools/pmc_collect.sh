@@ -14,6 +14,6 @@ timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o p4
 # kernel trace, single group: the per-kernel averages are whole-batch launches, as in bench.py's stage timing
 timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o kt1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu "$@" > $OUT/kt1.log 2>&1 || exit 1
 unset ORBHIP_PARTS
-# kernel trace of the default run (three frame groups on three streams; launches of mixed size)
+# kernel trace of the default run (two frame groups on two streams; launches of mixed size)
 timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o kt -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu "$@" > $OUT/kt.log 2>&1
 ls $OUT
