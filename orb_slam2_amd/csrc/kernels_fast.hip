@@ -167,7 +167,9 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
                           xa + 4 * nd <= (level == 0 ? L.w : pitch);
     const int off = fastLoad ? tx0 - xa : 0;
     if (fastLoad) {
-        // lane = (row within a pass, dword); a pass covers 64 / nd rows (nd <= 18: at least 3)
+        // lane = (row within a pass, dword); a pass covers 64 / nd rows.  All of a lane's loads are issued
+        // before the first one is awaited: one after the other they would make up most of the wavefront's life.
+        constexpr int RPP_MIN = 64 / (TILE_PITCH / 4), MAX_PASSES = (TILE_ROWS + RPP_MIN - 1) / RPP_MIN;
         const int rpp = 64 / nd;
         const int rr = lane / nd, d = lane - rr * nd;
         if (rr < rpp) {
@@ -175,7 +177,13 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
             uint32_t* dst = (uint32_t*)&tile[rr * TILE_PITCH + 4 * d];
             const int64_t srcStep = (int64_t)rpp * pitch;
             const int dstStep = rpp * (TILE_PITCH / 4);
-            for (int r = rr; r < th; r += rpp, src += srcStep, dst += dstStep) *dst = *(const uint32_t*)src;
+            uint32_t v[MAX_PASSES];
+#pragma unroll
+            for (int k = 0; k < MAX_PASSES; k++)
+                if (rr + k * rpp < th) v[k] = *(const uint32_t*)(src + k * srcStep);
+#pragma unroll
+            for (int k = 0; k < MAX_PASSES; k++)
+                if (rr + k * rpp < th) dst[k * dstStep] = v[k];
         }
     } else {
         const uint8_t* src = img + (int64_t)(Y0 - 3) * pitch + tx0;
@@ -240,10 +248,13 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
             for (int p = 0; p < steps; p++, y += rowsPerStep, c += rowsPerStep * TILE_PITCH) {
                 // (lanes outside the cell read tile bytes that belong to no pixel of it; their result is masked)
                 const int v = c[0];
-                const int dS = v - c[3 * TILE_PITCH], dE = v - c[3], dN = v - c[-3 * TILE_PITCH], dW = v - c[-3];
-                const int hiV = min(max(dS, dN), max(dE, dW));  // > th: an adjacent compass pair is darker
-                const int loV = max(min(dS, dN), min(dE, dW));  // < -th: an adjacent compass pair is brighter
-                const bool pass = xin & (y < ch) & ((hiV > th) | (loV < -th));
+                const int pS = c[3 * TILE_PITCH], pE = c[3], pN = c[-3 * TILE_PITCH], pW = c[-3];
+                // an adjacent compass pair darker than v - th, or one brighter than v + th: eight compares whose
+                // results are combined as lane masks on the scalar unit
+                const int lo = v - th, hi = v + th;
+                const bool darker = ((pS < lo) | (pN < lo)) & ((pE < lo) | (pW < lo));
+                const bool brighter = ((pS > hi) | (pN > hi)) & ((pE > hi) | (pW > hi));
+                const bool pass = xin & (y < ch) & (darker | brighter);
                 const unsigned long long m = __ballot(pass);
                 if (pass) cand[(tail + __popcll(m & below)) & 127] = (uint16_t)(lx | (y << 8));
                 tail += __popcll(m);
