@@ -151,7 +151,8 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_per_kernel.json")
     if os.path.exists(pmc_path) and dom != "pyramid" and args.width == 640 and args.height == 480 and args.nfeatures == 1000:
         with open(pmc_path) as fh:
-            pk = json.load(fh).get(kernel_name)
+            table = json.load(fh)
+        pk = next((v for k, v in table.items() if kernel_name in k), None)  # (template instances carry their arguments)
         if pk:
             k = B / pk["batch"]
             cn = pk["counters_per_launch"]
