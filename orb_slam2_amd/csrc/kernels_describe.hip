@@ -126,6 +126,7 @@ static __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+typedef float float2v __attribute__((ext_vector_type(2)));  // element-wise products and sums: v_pk_mul_f32 / v_pk_add_f32
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
 // sum of the two 16-bit products of a and b, plus c (v_dot2_u32_u16)
 static __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c) {
@@ -338,24 +339,33 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     const uint32_t wE0 = k0 | (k1 << 16), wE1 = k2 | (k3 << 16), wE2 = k2 | (k1 << 16), wE3 = k0;
     const uint32_t wO0 = k0 << 16, wO1 = k1 | (k2 << 16), wO2 = k3 | (k2 << 16), wO3 = k1 | (k0 << 16);
     if (rr < HROWS) {
+        // HROWS is even: all rows of a lane have the parity of its first one
+        static_assert(HROWS % 2 == 0, "the tap words are chosen once per lane");
+        const bool odd = (rr & 1) != 0;
+        const uint32_t w0 = odd ? wO0 : wE0, w1 = odd ? wO1 : wE1, w2 = odd ? wO2 : wE2, w3 = odd ? wO3 : wE3;
 #pragma unroll 1
         for (int r = rr; r < BL_N; r += HROWS) {
-            const bool odd = (r & 1) != 0;
-            const uint32_t w0 = odd ? wO0 : wE0, w1 = odd ? wO1 : wE1, w2 = odd ? wO2 : wE2, w3 = odd ? wO3 : wE3;
             const uint32_t* p = hb32 + __umul24((unsigned)(r >> 1), HB_P) + 4 * qi;
             const uint4 e0 = *(const uint4*)p, e1 = *(const uint4*)(p + HB_P), e2 = *(const uint4*)(p + 2 * HB_P),
                         e3 = *(const uint4*)(p + 3 * HB_P);
             const uint32_t c0[4] = {e0.x, e0.y, e0.z, e0.w}, c1[4] = {e1.x, e1.y, e1.z, e1.w};
             const uint32_t c2[4] = {e2.x, e2.y, e2.z, e2.w}, c3[4] = {e3.x, e3.y, e3.z, e3.w};
-            uint32_t packed = 0;
+            uint32_t v[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                uint32_t v = dot2_u16(c0[c], w0, 32768u);
-                v = dot2_u16(c1[c], w1, v);
-                v = dot2_u16(c2[c], w2, v);
-                v = dot2_u16(c3[c], w3, v);
-                v >>= 16;
-                packed |= (v > 255u ? 255u : v) << (8 * c);
+                v[c] = dot2_u16(c0[c], w0, 32768u);
+                v[c] = dot2_u16(c1[c], w1, v[c]);
+                v[c] = dot2_u16(c2[c], w2, v[c]);
+                v[c] = dot2_u16(c3[c], w3, v[c]);
+            }
+            uint32_t packed;
+            if (legacy) {  // these taps sum to 257: the rounded value can pass 255
+                packed = 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) packed |= min(v[c] >> 16, 255u) << (8 * c);
+            } else {       // taps summing to 256 cannot: (255 * 256 * 256 + 2^15) >> 16 == 255; the pixel is byte 2
+                packed = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u),
+                                               __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), 0x05040100u);
             }
             bl32[r * (BL_P / 4) + q] = packed;
         }
@@ -367,18 +377,27 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float a, b;
     sincos_portable(__fmul_rn(angle, factorPI), &b, &a);
+    // Rounding to the nearest integer, ties to even (cvRound), by adding 1.5 * 2^23: the sum's low mantissa bits
+    // are 2^22 + the rounded value, for any |value| < 2^22.  The 24-bit multiply-add below takes those bits
+    // as they are; what the constant contributes is subtracted once, together with the window's centre.
+    const float magic = 12582912.f;
+    const uint32_t magicBits = 0x4B400000u, magicLow = 0x400000u;
+    const uint32_t bias = magicLow * BL_P + magicBits - (18u * BL_P + 18u);
     unsigned long long words[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int pair = 64 * r + lane;
         const float4 pt = ((const float4*)c_pattern)[pair];
         const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
-        const int dy0 = (int)rintf(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        const int dx0 = (int)rintf(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        const int dy1 = (int)rintf(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        const int dx1 = (int)rintf(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        const int t0 = bl[__mul24(18 + dy0, BL_P) + 18 + dx0];
-        const int t1 = bl[__mul24(18 + dy1, BL_P) + 18 + dx1];
+        // (y, x) offsets of the two rotated test points, each product and sum rounded on its own
+        const float fy0 = __fadd_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)), magic);
+        const float fx0 = __fadd_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)), magic);
+        const float fy1 = __fadd_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)), magic);
+        const float fx1 = __fadd_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)), magic);
+        const uint32_t i0 = __umul24(__float_as_uint(fy0), BL_P) + __float_as_uint(fx0) - bias;
+        const uint32_t i1 = __umul24(__float_as_uint(fy1), BL_P) + __float_as_uint(fx1) - bias;
+        const int t0 = bl[i0];
+        const int t1 = bl[i1];
         words[r] = __ballot(t0 < t1);
     }
     if (lane == 0) {
