@@ -25,9 +25,9 @@
 #define BL_N 37
 #define BL_P 44
 
-// the 256 test pairs (x0, y0, x1, y1) of src/ORBextractor.cc:105-362, kept as floats for the rotation
+// the 256 test pairs of src/ORBextractor.cc:105-362 as (x0, x1, y0, y1), kept as floats for the rotation
 __constant__ __attribute__((aligned(16))) float c_pattern[256 * 4] = {
-#include "orb_pattern.inc"
+#include "orb_pattern_xxyy.inc"
 };
 
 static __device__ __forceinline__ int reflect101(int i, int n) {
@@ -388,14 +388,13 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     for (int r = 0; r < 4; r++) {
         const int pair = 64 * r + lane;
         const float4 pt = ((const float4*)c_pattern)[pair];
-        const float x0 = pt.x, y0 = pt.y, x1 = pt.z, y1 = pt.w;
-        // (y, x) offsets of the two rotated test points, each product and sum rounded on its own
-        const float fy0 = __fadd_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)), magic);
-        const float fx0 = __fadd_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)), magic);
-        const float fy1 = __fadd_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)), magic);
-        const float fx1 = __fadd_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)), magic);
-        const uint32_t i0 = __umul24(__float_as_uint(fy0), BL_P) + __float_as_uint(fx0) - bias;
-        const uint32_t i1 = __umul24(__float_as_uint(fy1), BL_P) + __float_as_uint(fx1) - bias;
+        // both test points at once: (x0, x1) and (y0, y1) rotate to y = x*b + y*a, x = x*a - y*b, each product
+        // and sum rounded on its own (v_pk_mul_f32 / v_pk_add_f32 are element-wise)
+        const float2v xs = {pt.x, pt.y}, ys = {pt.z, pt.w};
+        const float2v fy = (xs * b + ys * a) + magic;
+        const float2v fx = (xs * a - ys * b) + magic;
+        const uint32_t i0 = __umul24(__float_as_uint(fy.x), BL_P) + __float_as_uint(fx.x) - bias;
+        const uint32_t i1 = __umul24(__float_as_uint(fy.y), BL_P) + __float_as_uint(fx.y) - bias;
         const int t0 = bl[i0];
         const int t1 = bl[i1];
         words[r] = __ballot(t0 < t1);
