@@ -15,7 +15,7 @@
 
 #include "orb_internal.h"
 
-#define DESC_WAVES 1
+#define DESC_WAVES 1  // wavefronts per workgroup; with one, a keypoint's LDS is free again as soon as its wavefront ends
 #define RAW_N 43
 #define RAW_P 48   // 12 dwords: a window row starting at any byte alignment fits
 #define HGROUPS 10 // 4-column groups that hold the 37 blurred columns off+3 .. off+39, from group (off+3)/4 on

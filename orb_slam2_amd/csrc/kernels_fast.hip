@@ -23,7 +23,7 @@
 
 #include "orb_internal.h"
 
-#define FAST_WAVES 1
+#define FAST_WAVES 1  // wavefronts per workgroup; with one, a cell's LDS is free again as soon as its wavefront ends
 // LDS geometry per wavefront, a template parameter of the kernel: the pixel tile holds the cell interior
 // plus a 3-pixel halo (plus up to 3 bytes of alignment slack per row and one spare row that the
 // two-rows-per-step walk may touch), the score tile the interior plus a zero rim.  Two instances: cells up
