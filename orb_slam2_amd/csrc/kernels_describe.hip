@@ -169,10 +169,13 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     // it (frame, level, keypoint, window addresses, loop bounds) in scalar registers
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int outCapFrame = g->outCapFrame, nlevels = g->nlevels;
-    const int64_t slotLocal = (int64_t)blockIdx.x * DESC_WAVES + wave;
-    if (slotLocal >= (int64_t)nframes * outCapFrame) return;
-    const int frame = frame0 + (int)(slotLocal / outCapFrame);
-    const int slot = (int)(slotLocal % outCapFrame);
+    // one keypoint slot per workgroup, a frame's slots on one XCD (its windows overlap: they meet in that L2)
+    static_assert(DESC_WAVES == 1, "the slot numbering assumes one wavefront per workgroup");
+    int frameLocal;
+    unsigned slotU;
+    if (!orb_xcd_map(blockIdx.x, (unsigned)outCapFrame, nframes, &frameLocal, &slotU)) return;
+    const int frame = frame0 + frameLocal;
+    const int slot = (int)slotU;
     int level = 0;
     for (int l = 1; l < nlevels; l++)
         if (slot >= g->lv[l].outBase) level = l;
@@ -420,8 +423,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
 
 int orb_launch_describe(const OrbBatch& b) {
     const OrbGeom& g = *b.h_geom;
-    const int64_t slots = (int64_t)b.nframes * g.outCapFrame;
-    const int64_t blocks = (slots + DESC_WAVES - 1) / DESC_WAVES;
+    const int64_t blocks = orb_xcd_grid(b.nframes, g.outCapFrame);
     hipLaunchKernelGGL(k_describe, dim3((unsigned)blocks), dim3(64 * DESC_WAVES), 0, (hipStream_t)b.stream, b.d_geom,
                        b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, b.nframes, b.d_selXY, b.d_selScore,
                        b.d_levelCount, b.d_kps, b.d_desc, b.capPerFrame, b.d_nOut, b.d_error);

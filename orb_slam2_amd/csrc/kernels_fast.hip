@@ -119,11 +119,14 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
     // the wavefront index is the same in all 64 lanes: telling the compiler so keeps everything derived from
     // it (frame, level, cell geometry, loop bounds) in scalar registers
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int64_t cellLocal = (int64_t)blockIdx.x * FAST_WAVES + wave;
+    // one cell per workgroup, a frame's cells on one XCD (neighbouring cells share halo pixels and cache lines)
+    static_assert(FAST_WAVES == 1, "the cell numbering assumes one wavefront per workgroup");
     const int cellsPerFrame = g->cellsPerFrame;
-    if (cellLocal >= (int64_t)nframes * cellsPerFrame) return;  // whole wave leaves; no workgroup barrier below
-    const int frame = frame0 + (int)(cellLocal / cellsPerFrame);
-    const int c = (int)(cellLocal % cellsPerFrame);
+    int frameLocal;
+    unsigned cellU;
+    if (!orb_xcd_map(blockIdx.x, (unsigned)cellsPerFrame, nframes, &frameLocal, &cellU)) return;
+    const int frame = frame0 + frameLocal;
+    const int c = (int)cellU;
     const int64_t cellGlobal = (int64_t)frame * cellsPerFrame + c;
     int level = 0;
     for (int l = 1; l < g->nlevels; l++)
@@ -315,8 +318,7 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
 
 int orb_launch_fast(const OrbBatch& b) {
     const OrbGeom& g = *b.h_geom;
-    const int64_t cells = (int64_t)b.nframes * g.cellsPerFrame;
-    const int64_t blocks = (cells + FAST_WAVES - 1) / FAST_WAVES;
+    const int64_t blocks = orb_xcd_grid(b.nframes, g.cellsPerFrame);
     // (orb_api.hip refuses geometries whose cells exceed 59 x 59 before anything is launched)
     if (g.maxCellW <= TileSmall::MAX_W && g.maxCellH <= TileSmall::MAX_H)
         hipLaunchKernelGGL(k_fast_cells<TileSmall>, dim3((unsigned)blocks), dim3(64 * FAST_WAVES), 0, (hipStream_t)b.stream,

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
                                                       int64_t sFrame, uint8_t* __restrict__ dst, int dw, int dh,
                                                       int dpitch, int64_t dFrame, const void* __restrict__ xtab,
                                                       const void* __restrict__ ytab, double scaleX, double scaleY,
-                                                      int tp, int rowsMax) {
+                                                      int tp, int rowsMax, int tilesX, int tilesY, int nframes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
     const int t = threadIdx.x;
     RsTileCtx c;
@@ -147,7 +147,12 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
     c.tp = tp;
     c.dx = t & 63;
     c.q = __builtin_amdgcn_readfirstlane(t >> 6);  // wavefront index: uniform
-    const int x0 = blockIdx.x * ORB_RS_TW, x1 = min(x0 + ORB_RS_TW, dw);
+    // tiles of one frame on one XCD: neighbouring tiles share source rows and cache lines
+    int frameLocal;
+    unsigned tileId;
+    if (!orb_xcd_map(blockIdx.x, (unsigned)(tilesX * tilesY), nframes, &frameLocal, &tileId)) return;
+    const int bx = (int)(tileId % (unsigned)tilesX), by = (int)(tileId / (unsigned)tilesX);
+    const int x0 = bx * ORB_RS_TW, x1 = min(x0 + ORB_RS_TW, dw);
     c.colValid = x0 + c.dx < dw;
     OrbAreaTap txa = {};
     OrbLinTap txl = {};
@@ -159,8 +164,8 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
     orb_resize_span(x0, x1, scaleX, sw, &sx0, &sx1);
     c.sxa = sx0 & ~3;
     const int nd = (sx1 - c.sxa + 4) >> 2;
-    const uint8_t* S = src + (int64_t)blockIdx.z * sFrame;
-    uint8_t* D = dst + (int64_t)blockIdx.z * dFrame;
+    const uint8_t* S = src + (int64_t)frameLocal * sFrame;
+    uint8_t* D = dst + (int64_t)frameLocal * dFrame;
     const bool aligned = (sstride & 3) == 0 && (((unsigned long long)S) & 3ull) == 0;
     // staging: thread = (row within a pass, dword); a pass covers 256 / nd rows (nd <= 256: checked by the launcher)
     const int rpp = 256 / nd;
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
     };
 
     if (!PAIR) {
-        const int y0 = blockIdx.y * ORB_RS_TH;
+        const int y0 = by * ORB_RS_TH;
         int sy0, nrows;
         rows_of(y0, &sy0, &nrows);
         stage_taps(y0);
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
         return;
     }
 
-    int y0 = blockIdx.y * (RS_TILES_PER_WG * ORB_RS_TH);
+    int y0 = by * (RS_TILES_PER_WG * ORB_RS_TH);
     int sy0, nrows;
     rows_of(y0, &sy0, &nrows);
     uint32_t held[RS_STAGE_REGS];
@@ -312,10 +317,12 @@ static int launch_resize(bool area, int ntaps, const uint8_t* src, int sw, int s
     // two tiles per workgroup when one tile is at most RS_STAGE_REGS dwords per thread (any level ratio up to ~1.5)
     const int rowsPerPass = 256 / (tp / 4);
     const bool pair = (rows + rowsPerPass - 1) / rowsPerPass <= RS_STAGE_REGS && tilesY > 1;
-    dim3 grid((dw + ORB_RS_TW - 1) / ORB_RS_TW, pair ? (tilesY + RS_TILES_PER_WG - 1) / RS_TILES_PER_WG : tilesY, nframes);
+    const int tilesX = (dw + ORB_RS_TW - 1) / ORB_RS_TW;
+    const int tilesYwg = pair ? (tilesY + RS_TILES_PER_WG - 1) / RS_TILES_PER_WG : tilesY;
+    const dim3 grid((unsigned)orb_xcd_grid(nframes, (int64_t)tilesX * tilesYwg));
 #define RS_LAUNCH(AREA_, NT_, PAIR_)                                                                                  \
     hipLaunchKernelGGL((k_resize_tiled<AREA_, NT_, PAIR_>), grid, dim3(256), lds, st, src, sw, sh, sstride, sFrame, dst, \
-                       dw, dh, dpitch, dFrame, xt, yt, scaleX, scaleY, tp, rows)
+                       dw, dh, dpitch, dFrame, xt, yt, scaleX, scaleY, tp, rows, tilesX, tilesYwg, nframes)
     if (area && ntaps <= 3) {
         if (pair) RS_LAUNCH(true, 3, true); else RS_LAUNCH(true, 3, false);
     } else if (area) {

@@ -95,6 +95,25 @@ static inline void orb_resize_tile_extent(int ssize, int dsize, double scale, in
     *extent = best;
 }
 
+// Workgroups are dealt round robin over the 8 XCDs (workgroups b and b + 8 share one), each with an L2 of
+// its own.  Kernels whose workgroups read overlapping pieces of one frame (cell halos, keypoint windows,
+// source rows that straddle tiles) number their work so that a frame stays on one XCD: workgroup b takes
+// item (b / 8) % perFrame of frame (b % 8) + 8 * ((b / 8) / perFrame).  The grid covers
+// 8 * ceil(nframes / 8) frames; workgroups of frames beyond nframes leave at once.
+#define ORB_XCDS 8
+#ifdef __HIPCC__
+static __device__ __forceinline__ bool orb_xcd_map(unsigned b, unsigned perFrame, int nframes, int* frameLocal,
+                                                   unsigned* item) {
+    const unsigned j = b / ORB_XCDS, k = j / perFrame;
+    *item = j - k * perFrame;
+    *frameLocal = (int)(b % ORB_XCDS + ORB_XCDS * k);
+    return *frameLocal < nframes;
+}
+#endif
+static inline int64_t orb_xcd_grid(int nframes, int64_t perFrame) {
+    return (int64_t)ORB_XCDS * ((nframes + ORB_XCDS - 1) / ORB_XCDS) * perFrame;
+}
+
 // Quadtree node as the kernel keeps it (keys of a node are a contiguous range of the code-sorted key array).
 struct OrbNode {
     int lo, hi;      // key range [lo, hi)
