@@ -157,7 +157,9 @@ def main():
             k = B / pk["batch"]
             cn = pk["counters_per_launch"]
             if "FETCH_SIZE" in cn and "WRITE_SIZE" in cn:
-                traffic = int((cn["FETCH_SIZE"] + cn["WRITE_SIZE"]) * 1024 * k)
+                # counter unit KB; gfx950 tallies a 128-byte read request as 64 bytes (tools/fetch_calib.hip
+                # reads 512 MiB with 4- and 16-byte loads per lane: FETCH_SIZE reports 256 MiB, WRITE_SIZE is exact)
+                traffic = int((2 * cn["FETCH_SIZE"] + cn["WRITE_SIZE"]) * 1024 * k)
             if "SQ_INSTS_VALU" in cn:
                 wi = cn["SQ_INSTS_VALU"] * k
                 # one wave-instruction holds a SIMD's 16-lane ALU for 4 cycles; 1024 SIMDs at 2.4 GHz

@@ -6,8 +6,11 @@ out.json holds, per kernel, the mean counters per launch and the batch size they
 bench.py scales them to its own batch for the roofline's `traffic` and VALU-issue fields.
 
 Derived lines: VALU issue utilisation assumes one wave-instruction occupies a SIMD for 4 cycles
-(64 lanes over 16-lane ALUs) on 1024 SIMDs at 2.4 GHz; FETCH_SIZE / WRITE_SIZE are reported by
-the hardware in units of 32 B / 64 B transactions as noted in the header of the output.
+(64 lanes over 16-lane ALUs) on 1024 SIMDs at 2.4 GHz.  FETCH_SIZE / WRITE_SIZE are in KB;
+on gfx950 FETCH_SIZE counts half the bytes of coalesced reads (128-byte requests tallied as
+64 bytes), for 4-byte-per-lane loads as for 16-byte ones, and WRITE_SIZE is exact:
+tools/fetch_calib.hip measures both on a 512 MiB buffer (profiles/r01_fetch_calibration.txt).
+The summary line therefore doubles FETCH_SIZE; the raw counter values are listed as collected.
 """
 import csv
 import sys
@@ -50,8 +53,8 @@ def main():
                 100 * util, m["SQ_INSTS_VALU"] / w, m.get("SQ_INSTS_SALU", 0) / w, m.get("SQ_INSTS_LDS", 0) / w,
                 m.get("SQ_INSTS_VMEM_RD", 0) / w, m.get("SQ_INSTS_VMEM_WR", 0) / w))
         if "FETCH_SIZE" in m or "WRITE_SIZE" in m:
-            lines.append("    HBM-side traffic per launch: fetch %.1f MB, write %.1f MB (counter unit KB; dword/byte access patterns, no 2x correction applied)" % (
-                m.get("FETCH_SIZE", 0) * 1024 / 1e6, m.get("WRITE_SIZE", 0) * 1024 / 1e6))
+            lines.append("    memory-side traffic per launch: fetch %.1f MB (2 x FETCH_SIZE, see tools/fetch_calib.hip), write %.1f MB" % (
+                2 * m.get("FETCH_SIZE", 0) * 1024 / 1e6, m.get("WRITE_SIZE", 0) * 1024 / 1e6))
         if "SQ_LDS_IDX_ACTIVE" in m:
             lines.append("    LDS busy %.1f %% of CU-cycles (256 CUs)" % (100 * m["SQ_LDS_IDX_ACTIVE"] / (256 * 2.4 * d)))
     open(out, "w").write("\n".join(lines) + "\n")
