@@ -1,6 +1,8 @@
 #!/bin/bash
 # Collects SQ counters for a short bench run in separate rocprofv3 passes (run on the GPU box).
 # usage: tools/pmc_collect.sh <outdir under gpurun_out> [bench args...]
+# then:  python tools/pmc_summary.py profiles/r01_pmc_per_kernel.txt profiles/r01_pmc_per_kernel.json <bench batch, 512 by default> \
+#            gpurun_out/<outdir>/p{1,2,3,4}_counter_collection.csv
 set -e
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $OUT
