@@ -200,6 +200,36 @@ def test_extract_after_sparse_frames(hip, oracle):
     c.close()
 
 
+def test_repeated_batches_are_identical(hip):
+    """The same batch over and over (frame groups on two streams, LDS-resident stages, the asynchronous
+    key-count read-back that resizes the quadtree's LDS block): every repetition must be bit-identical."""
+    import torch
+
+    n, w, h = 40, 640, 480
+    c = _ctx(hip, "fork", batch=n)
+    frames = np.stack([synth_scene(w, h, frame_seed(1, 60 + f % 10)) for f in range(n)])
+    d_imgs = torch.from_numpy(frames).cuda()
+    cap = c.cap
+    outs = [torch.zeros((n, cap, 28), dtype=torch.uint8, device="cuda"), torch.zeros((n, cap, 32), dtype=torch.uint8, device="cuda"),
+            torch.zeros(n, dtype=torch.int32, device="cuda")]
+    ref = None
+    for step in range(300):
+        for t in outs[:2]:
+            t.fill_(0xAB)
+        c.extract_batch_device(d_imgs, *outs)
+        if step % 20 == 0 or step == 299:
+            torch.cuda.synchronize()
+            c.check_last_batch()
+            mask = torch.arange(cap, device="cuda")[None, :] < outs[2][:, None]
+            cur = [outs[0] * mask[:, :, None], outs[1] * mask[:, :, None], outs[2].clone()]
+            if ref is None:
+                ref = cur
+            else:
+                for a, b in zip(cur, ref):
+                    assert torch.equal(a, b), "step %d differs from step 0" % step
+    c.close()
+
+
 def test_extract_device_entry_point(hip, oracle):
     import torch
 
