@@ -194,7 +194,24 @@ int orb_launch_quadtree(const OrbBatch& b) {
     // keys in LDS: the largest level met so far plus an eighth; the full block until a count has arrived
     int ldsKeys = QT_LDS_KEYS_MAX;
     if (b.qtKeysSeen > 0) ldsKeys = std::min(QT_LDS_KEYS_MAX, std::max(512, (b.qtKeysSeen + b.qtKeysSeen / 8 + 63) & ~63));
-    const QtLaunch q = qt_plan(g, 0, g.nlevels, ldsKeys);
+    QtLaunch q = qt_plan(g, 0, g.nlevels, ldsKeys);
+    if (q.ldsKeys > 0 && q.ldsKeys < QT_LDS_KEYS_MAX) {
+        // The block decides how many workgroups a CU holds; between two such steps a larger block costs
+        // nothing, so the keys get all the room up to the next step (measured: four blocks of 40 908 bytes
+        // fit the 160 KB of a CU, four of 41 036 do not; sizes are rounded up to 512 bytes here to stay clear
+        // of the allocation granularity).
+        const size_t unit = 512, perCU = 160 * 1024;
+        auto block_bytes = [&](const QtLaunch& p) {
+            return (sizeof(QtShared) + (size_t)p.ldsKeys * 8 + (size_t)p.regionInts * 4 + unit - 1) / unit * unit;
+        };
+        const size_t wgs = perCU / block_bytes(q);
+        if (wgs >= 1) {
+            const size_t room = perCU / wgs / unit * unit;
+            const int more = (int)((room - block_bytes(q)) / 8);
+            const QtLaunch q2 = qt_plan(g, 0, g.nlevels, std::min(QT_LDS_KEYS_MAX, q.ldsKeys + more));
+            if (q2.ldsKeys > 0 && block_bytes(q2) <= room) q = q2;
+        }
+    }
     const size_t lds = (size_t)q.ldsKeys * 8 + (size_t)q.regionInts * 4;
     hipLaunchKernelGGL(k_quadtree, dim3(b.nframes * q.nlevels), dim3(threads), lds, (hipStream_t)b.stream, b.d_geom, q,
                        b.frame0, b.nframes, b.d_cellKeys, b.d_cellCount, b.d_sort, b.d_nodes, b.d_ints, b.d_selXY, b.d_selScore, b.d_levelCount,

@@ -68,7 +68,11 @@ QT_FN uint32_t qt_entry_prio(unsigned long long e) {
 }
 
 struct QtShared {
-    int part[64];    // per-wavefront partial sums of the block scan
+    // per-wavefront partial sums of the block scans: ints (qt_scan) or three counts packed into one word (qt_scan3)
+    union {
+        int part[64];
+        unsigned long long part3[16];
+    };
     int bigList[QT_BIG_LIST];
     int nBig;
     unsigned best32;
@@ -185,6 +189,53 @@ QT_FN void qt_scan(int* a, int n, QtShared* sh) {
     for (int i = b; i < e; i++) {
         const int v = a[i];
         a[i] = run;
+        run += v;
+    }
+    QT_BARRIER();
+}
+
+// Three exclusive prefix sums at once: a, b (and c unless null) hold small non-negative counts whose
+// totals stay below 2^21; they travel packed in one 64-bit word, so the three scans cost one pass over
+// the data, one shuffle ladder and two barriers.  a[n], b[n], c[n] receive the totals.
+QT_FN void qt_scan3(int* a, int* b, int* c, int n, QtShared* sh) {
+    const int T = QT_NT, t = QT_TID;
+    const int chunk = (n + T - 1) / T;
+    const int lo = t * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+    unsigned long long s = 0ull;
+    for (int i = lo; i < hi; i++)
+        s += (unsigned long long)a[i] | ((unsigned long long)b[i] << 21) | ((unsigned long long)(c ? c[i] : 0) << 42);
+#ifdef ORB_HOST_EMU
+    unsigned long long run = 0ull;
+    const unsigned long long total = s;
+#else
+    const int lane = t & 63, wv = t >> 6, nw = (T + 63) >> 6;
+    unsigned long long incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned vl = (unsigned)__shfl_up((int)(unsigned)incl, o, 64);
+        const unsigned vh = (unsigned)__shfl_up((int)(unsigned)(incl >> 32), o, 64);
+        if (lane >= o) incl += ((unsigned long long)vh << 32) | vl;
+    }
+    if (lane == 63) sh->part3[wv] = incl;
+    QT_BARRIER();
+    unsigned long long wprefix = 0ull, total = 0ull;
+    for (int i = 0; i < nw; i++) {
+        const unsigned long long v = sh->part3[i];
+        if (i < wv) wprefix += v;
+        total += v;
+    }
+    unsigned long long run = wprefix + incl - s;
+#endif
+    if (t == 0) {
+        a[n] = (int)(total & 0x1fffffull);
+        b[n] = (int)((total >> 21) & 0x1fffffull);
+        if (c) c[n] = (int)(total >> 42);
+    }
+    for (int i = lo; i < hi; i++) {
+        const unsigned long long v = (unsigned long long)a[i] | ((unsigned long long)b[i] << 21) | ((unsigned long long)(c ? c[i] : 0) << 42);
+        a[i] = (int)(run & 0x1fffffull);
+        b[i] = (int)((run >> 21) & 0x1fffffull);
+        if (c) c[i] = (int)(run >> 42);
         run += v;
     }
     QT_BARRIER();
@@ -310,9 +361,7 @@ QT_FN void qt_distribute(const QtWork& w, int n, int nIni, int N, int n3quirk, Q
             w.scanC[i] = nm;
         }
         QT_BARRIER();
-        qt_scan(w.scanA, nL, sh);
-        qt_scan(w.scanB, nL, sh);
-        qt_scan(w.scanC, nL, sh);
+        qt_scan3(w.scanA, w.scanB, w.scanC, nL, sh);
         const int totalChildren = w.scanA[nL], nToExpand = w.scanB[nL], nStay = w.scanC[nL];
         if (totalChildren + nStay > w.nodeCap) {  // cannot happen by the size bound; fail loudly
             if (t == 0) { sh->err = 2; sh->finish = 1; }
@@ -380,8 +429,7 @@ QT_FN void qt_distribute(const QtWork& w, int n, int nIni, int N, int n3quirk, Q
             }
             if (t == 0) sh->stop = nR - 1;
             QT_BARRIER();
-            qt_scan(w.scanA, nR, sh);
-            qt_scan(w.scanB, nR, sh);
+            qt_scan3(w.scanA, w.scanB, nullptr, nR, sh);
             // the list reaches the quota after processing node j when nLf + (children - parents) >= N
             for (int j = t; j < nR; j += T) {
                 const int after = nLf + w.scanA[j + 1] - (j + 1);
