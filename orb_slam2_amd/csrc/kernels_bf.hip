@@ -42,14 +42,6 @@ struct orb_bf {
     int variant = -1;
 };
 
-#define HIP_TRY(call)                                                                                   \
-    do {                                                                                                \
-        hipError_t e_ = (call);                                                                         \
-        if (e_ != hipSuccess) {                                                                         \
-            orb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);   \
-            return ORB_ERR_HIP;                                                                         \
-        }                                                                                               \
-    } while (0)
 
 // popcount(x) + acc in one instruction; written as asm because the compiler
 // otherwise splits the chain into bcnt(x, 0) plus separate three-operand adds.

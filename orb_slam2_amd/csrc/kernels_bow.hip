@@ -34,14 +34,6 @@
 #include "match_common.h"
 #include "orb_internal.h"
 
-#define HIP_TRY(call)                                                                                   \
-    do {                                                                                                \
-        hipError_t e_ = (call);                                                                         \
-        if (e_ != hipSuccess) {                                                                         \
-            orb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);   \
-            return ORB_ERR_HIP;                                                                         \
-        }                                                                                               \
-    } while (0)
 
 #define BOW_MAX_FEATURES 8192   // features of one frame (taken flags: 128 per lane)
 #define VOC_GROUP 16            // lanes that share one descriptor during the descent

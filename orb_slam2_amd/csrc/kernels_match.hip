@@ -35,14 +35,6 @@
 #define M_MAXKP 8192          // keypoints per frame the LDS state is sized for
 #define M_CELLS (ORB_GRID_COLS * ORB_GRID_ROWS)
 
-#define HIP_TRY(call)                                                                                   \
-    do {                                                                                                \
-        hipError_t e_ = (call);                                                                         \
-        if (e_ != hipSuccess) {                                                                         \
-            orb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);   \
-            return ORB_ERR_HIP;                                                                         \
-        }                                                                                               \
-    } while (0)
 
 
 // Frame::mnMinX .. mnMaxY and the grid element inverses (upstream Frame.cc constructor tail).

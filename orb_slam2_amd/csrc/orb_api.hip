@@ -25,14 +25,6 @@ void orb_set_error(const char* fmt, ...) {
 extern "C" const char* orb_last_error(void) { return t_err; }
 extern "C" const char* orb_version(void) { return "orbhip 0.1 (gfx950)"; }
 
-#define HIP_TRY(call)                                                                  \
-    do {                                                                               \
-        hipError_t e_ = (call);                                                        \
-        if (e_ != hipSuccess) {                                                        \
-            orb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return ORB_ERR_HIP;                                                        \
-        }                                                                              \
-    } while (0)
 
 static inline int cv_round(float v) { return (int)lrintf(v); }
 static inline int cv_floor(double v) {

@@ -165,3 +165,13 @@ int orb_launch_distinctive(const uint8_t* d_desc, const int* d_offsets, int npoi
                            int* d_median, void* stream);
 
 void orb_set_error(const char* fmt, ...);
+
+// For host functions that return an ORB_* code: a failing HIP call records its message and returns ORB_ERR_HIP.
+#define HIP_TRY(call)                                                                                 \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            orb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return ORB_ERR_HIP;                                                                       \
+        }                                                                                             \
+    } while (0)
