@@ -97,21 +97,25 @@ static inline void orb_resize_tile_extent(int ssize, int dsize, double scale, in
 
 // Workgroups are dealt round robin over the 8 XCDs (workgroups b and b + 8 share one), each with an L2 of
 // its own.  Kernels whose workgroups read overlapping pieces of one frame (cell halos, keypoint windows,
-// source rows that straddle tiles) number their work so that a frame stays on one XCD: workgroup b takes
-// item (b / 8) % perFrame of frame (b % 8) + 8 * ((b / 8) / perFrame).  The grid covers
-// 8 * ceil(nframes / 8) frames; workgroups of frames beyond nframes leave at once.
+// source rows that straddle tiles) number their work so that a frame stays on one XCD: with X = 8 lanes
+// of frames, workgroup b takes item (b / X) % perFrame of frame (b % X) + X * ((b / X) / perFrame).  The
+// grid covers X * ceil(nframes / X) frames; workgroups of frames beyond nframes leave at once.  Fewer than
+// 8 frames use X = nframes: nothing is launched in vain, and a single frame spreads over all XCDs.
 #define ORB_XCDS 8
+static inline ORB_HD unsigned orb_xcd_lanes(int nframes) { return nframes < ORB_XCDS ? (unsigned)nframes : ORB_XCDS; }
 #ifdef __HIPCC__
 static __device__ __forceinline__ bool orb_xcd_map(unsigned b, unsigned perFrame, int nframes, int* frameLocal,
                                                    unsigned* item) {
-    const unsigned j = b / ORB_XCDS, k = j / perFrame;
+    const unsigned X = orb_xcd_lanes(nframes);
+    const unsigned j = b / X, k = j / perFrame;
     *item = j - k * perFrame;
-    *frameLocal = (int)(b % ORB_XCDS + ORB_XCDS * k);
+    *frameLocal = (int)(b - j * X + X * k);
     return *frameLocal < nframes;
 }
 #endif
 static inline int64_t orb_xcd_grid(int nframes, int64_t perFrame) {
-    return (int64_t)ORB_XCDS * ((nframes + ORB_XCDS - 1) / ORB_XCDS) * perFrame;
+    const int64_t X = orb_xcd_lanes(nframes);
+    return X * ((nframes + X - 1) / X) * perFrame;
 }
 
 // Quadtree node as the kernel keeps it (keys of a node are a contiguous range of the code-sorted key array).
