@@ -187,6 +187,52 @@ int orb_match_projected(orb_ctx* ctx, const float* u, const float* v, const floa
                         const orb_keypoint* k2, const uint8_t* d2, int n2, int img_w, int img_h,
                         const uint8_t* occupied2, int* match2, int th_high, int check_ori, int* nmatches);
 
+/* The overloads below are declared by the reference (include/ORBmatcher.h) and
+ * defined nowhere in it; their candidate loops follow upstream ORB-SLAM2, of
+ * which the fork is a copy, and the steps listed in the header's comments.
+ * As with orb_match_projected the caller does the pose algebra and passes
+ * pixels, radii and level ranges; the window query is Frame::GetFeaturesInArea
+ * as the context's quirks configure it.
+ *
+ * Other overloads map onto orb_match_projected as it stands:
+ * SearchByProjection(Frame&, KeyFrame*, sAlreadyFound, th, ORBdist)
+ * (include/ORBmatcher.h:75): levels [l-1, l+1], occupied2 = keypoints that
+ * hold any map point, qobs all 1, th_high = ORBdist, check_ori as configured;
+ * SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th) (:90): levels
+ * [l-1, l], occupied2 = entries of vpMatched already set, qobs all 1,
+ * th_high = TH_LOW, check_ori 0. */
+
+/* Kernel-level form of SearchByProjection(Frame&, const vector<MapPoint*>&, th)
+ * (include/ORBmatcher.h:24-39, tracking of the local map): per query the
+ * projection (u,v) = (mTrackProjX, mTrackProjY), radius = r * scale factor of the
+ * predicted level, levels [predicted-1, predicted], the map point's descriptor
+ * and qobs = "has observations".  Keypoints that hold an observed map point are
+ * skipped (occupied2 on entry, then whatever earlier queries stored); best and
+ * second-best distance are kept with their levels; a best distance <= th_high
+ * is accepted unless both lie on the same level and best > nnratio * second.
+ * No rotation check.  match2 as in orb_match_projected (-1 or the query). */
+int orb_match_local_map(orb_ctx* ctx, const float* u, const float* v, const float* radius, const int* min_level,
+                        const int* max_level, const uint8_t* qdesc, const uint8_t* qobs, int nq, const orb_keypoint* k2,
+                        const uint8_t* d2, int n2, int img_w, int img_h, const uint8_t* occupied2, int* match2,
+                        int th_high, float nnratio, int* nmatches);
+
+/* Candidate loop shared by Fuse(KeyFrame*, vpMapPoints, th), Fuse(KeyFrame*,
+ * Scw, vpPoints, th, vpReplacePoint) (include/ORBmatcher.h:163-184) and
+ * SearchBySim3 (:146-160): every query on its own takes the keypoint of
+ * smallest descriptor distance in its window and level range (first in window
+ * order among equals); best_idx[i] = that keypoint when the distance is <= th
+ * (TH_LOW for Fuse, TH_HIGH for SearchBySim3), else -1; best_dist[i] (may be
+ * NULL) = the distance, 256 when the window was empty.  inv_level_sigma2 != NULL
+ * (nlevels entries, mvInvLevelSigma2) adds the monocular reprojection gate of
+ * the first Fuse overload: a candidate whose squared pixel distance to (u,v)
+ * times the inverse sigma^2 of its level exceeds chi2_max (5.99) is left out.
+ * What to do with the result (replace, add observation, mutual agreement of
+ * the two SearchBySim3 directions) is map surgery on host objects. */
+int orb_match_best(orb_ctx* ctx, const float* u, const float* v, const float* radius, const int* min_level,
+                   const int* max_level, const uint8_t* qdesc, int nq, const orb_keypoint* k2, const uint8_t* d2, int n2,
+                   int img_w, int img_h, const float* inv_level_sigma2, int nlevels, double chi2_max, int th,
+                   int* best_idx, int* best_dist);
+
 /* MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:158-222, for npoints
  * map points at once.  desc holds every point's observation descriptors back
  * to back (32 bytes each), point p owning rows offsets[p] .. offsets[p+1]-1 in
@@ -292,6 +338,19 @@ int orb_match_bow(orb_ctx* ctx, const orb_keypoint* kf_keys_un, const uint8_t* k
                   const orb_keypoint* f_keys, const uint8_t* f_desc, int nf, const int* f_fv_node,
                   const int* f_fv_offsets, const int* f_fv_index, int f_nfv, float nnratio, int check_ori,
                   int* match_kf, int* nmatches);
+
+/* SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&) (include/ORBmatcher.h:110,
+ * loop detection; declared only, body as upstream ORB-SLAM2): as orb_match_bow
+ * with three differences: features of the second keyframe take part only where
+ * valid2 says they hold a good map point, the distance test is the strict
+ * bestDist1 < TH_LOW, and the result is indexed by the first keyframe's
+ * features: matches12[i] = feature of keyframe 2 whose map point feature i of
+ * keyframe 1 is matched to, -1 for none (n1 entries). */
+int orb_match_bow_keyframes(orb_ctx* ctx, const orb_keypoint* keys_un1, const uint8_t* desc1, const uint8_t* valid1,
+                            int n1, const int* fv_node1, const int* fv_offsets1, const int* fv_index1, int nfv1,
+                            const orb_keypoint* keys_un2, const uint8_t* desc2, const uint8_t* valid2, int n2,
+                            const int* fv_node2, const int* fv_offsets2, const int* fv_index2, int nfv2, float nnratio,
+                            int check_ori, int* matches12, int* nmatches);
 
 /* ---- measurement ------------------------------------------------------------ */
 

@@ -224,6 +224,42 @@ def search_by_projection(u, v, radius, min_level, max_level, qangle, qdesc, qobs
     return n, match2[: len(k2)]
 
 
+def search_local_map(u, v, radius, min_level, max_level, qdesc, qobs, k2, d2, img_w, img_h, occupied2=None, th_high=100, nnratio=0.8, quirks=QUIRKS_FORK):
+    """SearchByProjection(Frame&, const vector<MapPoint*>&, th) in kernel-level form: (nmatches, match2)."""
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    u, v, radius = f32(u), f32(v), f32(radius)
+    min_level, max_level = i32(min_level), i32(max_level)
+    qdesc, d2 = _u8(qdesc), _u8(d2)
+    qobs = _u8(qobs) if qobs is not None else None
+    occ = _u8(occupied2) if occupied2 is not None else None
+    k2 = np.ascontiguousarray(k2, dtype=KP_DTYPE)
+    match2 = np.zeros(max(len(k2), 1), dtype=np.int32)
+    n = lib().oro_search_local_map(
+        _p(u), _p(v), _p(radius), _p(min_level), _p(max_level), _p(qdesc), _p(qobs), len(u),
+        _p(k2), _p(d2), len(k2), img_w, img_h, _p(occ), _p(match2), th_high, C.c_float(nnratio), quirks,
+    )
+    return n, match2[: len(k2)]
+
+
+def search_best(u, v, radius, min_level, max_level, qdesc, k2, d2, img_w, img_h, inv_level_sigma2=None, chi2_max=5.99, th=50, quirks=QUIRKS_FORK):
+    """Candidate loop of Fuse / SearchBySim3: (best_idx, best_dist) per query."""
+    f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    u, v, radius = f32(u), f32(v), f32(radius)
+    min_level, max_level = i32(min_level), i32(max_level)
+    qdesc, d2 = _u8(qdesc), _u8(d2)
+    k2 = np.ascontiguousarray(k2, dtype=KP_DTYPE)
+    sig = f32(inv_level_sigma2) if inv_level_sigma2 is not None else None
+    idx = np.zeros(max(len(u), 1), dtype=np.int32)
+    dist = np.zeros(max(len(u), 1), dtype=np.int32)
+    lib().oro_search_best(
+        _p(u), _p(v), _p(radius), _p(min_level), _p(max_level), _p(qdesc), len(u), _p(k2), _p(d2), len(k2), img_w, img_h,
+        _p(sig), 0 if sig is None else len(sig), C.c_double(chi2_max), th, quirks, _p(idx), _p(dist),
+    )
+    return idx[: len(u)], dist[: len(u)]
+
+
 def bf_top2(q, db):
     q, db = _u8(q), _u8(db)
     nq, nd = len(q), len(db)
@@ -356,3 +392,17 @@ def search_by_bow(kf_keys_un, kf_desc, kf_valid, kf_fv, f_keys, f_desc, f_fv, nn
     n = lib().oro_search_by_bow(_p(kk), _p(kd), _p(kv), _p(a[0]), _p(a[1]), _p(a[2]), len(a[0]), _p(fk), _p(fd), len(fk),
                                 _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]), C.c_float(nnratio), int(check_ori), _p(match))
     return n, match[: len(fk)]
+
+
+def search_by_bow_keyframes(keys_un1, desc1, valid1, fv1, keys_un2, desc2, valid2, fv2, nnratio=0.75, check_ori=True):
+    """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, ...): returns (nmatches, matches12[n1])."""
+    k1 = np.ascontiguousarray(keys_un1, dtype=KP_DTYPE)
+    k2 = np.ascontiguousarray(keys_un2, dtype=KP_DTYPE)
+    d1, d2, v1, v2 = _u8(desc1), _u8(desc2), _u8(valid1), _u8(valid2)
+    a = [np.ascontiguousarray(x, dtype=np.int32) for x in fv1]
+    b = [np.ascontiguousarray(x, dtype=np.int32) for x in fv2]
+    match = np.full(max(len(k1), 1), -1, dtype=np.int32)
+    n = lib().oro_search_by_bow_keyframes(_p(k1), _p(d1), _p(v1), len(k1), _p(a[0]), _p(a[1]), _p(a[2]), len(a[0]),
+                                          _p(k2), _p(d2), _p(v2), len(k2), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]),
+                                          C.c_float(nnratio), int(check_ori), _p(match))
+    return n, match[: len(k1)]

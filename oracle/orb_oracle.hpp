@@ -128,6 +128,14 @@ int searchByProjection(const float* u, const float* v, const float* radius, cons
                        const uint8_t* occupied2, int* match2 /*n2, -1 or query idx*/, int thHigh, bool checkOri,
                        unsigned quirks);
 
+// Kernel-level forms of overloads the fork only declares (include/ORBmatcher.h:39,146-184); loops of upstream ORB-SLAM2.
+int searchLocalMap(const float* u, const float* v, const float* radius, const int* minLevel, const int* maxLevel,
+                   const uint8_t* qdesc, const uint8_t* qobs, int nq, const FrameGrid& F, const uint8_t* occupied2,
+                   int* match2, int thHigh, float nnratio, unsigned quirks);
+void searchBest(const float* u, const float* v, const float* radius, const int* minLevel, const int* maxLevel,
+                const uint8_t* qdesc, int nq, const FrameGrid& F, const float* invLevelSigma2, int nlevels,
+                double chi2Max, int th, unsigned quirks, int* bestIdxOut, int* bestDistOut);
+
 // MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:186-214: index of the descriptor with the least median
 // distance to the others (first on ties); *median receives that median.  selfDistance reproduces the fork's
 // DescriptorDistance(d[i], d[i]) at :195 (every distance 0).  Returns -1 for n == 0.
@@ -156,6 +164,12 @@ double scoreL1(const std::map<int, double>& v1, const std::map<int, double>& v2)
 int searchByBoW(const KeyPoint* kfKeysUn, const uint8_t* kfDesc, const uint8_t* kfValid,
                 const std::map<int, std::vector<unsigned> >& kfFeat, const KeyPoint* fKeys, const uint8_t* fDesc, int nF,
                 const std::map<int, std::vector<unsigned> >& fFeat, float nnratio, bool checkOri, int* matchKF);
+
+int searchByBoWKeyFrames(const KeyPoint* keysUn1, const uint8_t* desc1, const uint8_t* valid1, int n1,
+                         const std::map<int, std::vector<unsigned> >& feat1, const KeyPoint* keysUn2,
+                         const uint8_t* desc2, const uint8_t* valid2, int n2,
+                         const std::map<int, std::vector<unsigned> >& feat2, float nnratio, bool checkOri,
+                         int* matches12);
 
 void bruteForceTop2(const uint8_t* q, int nq, const uint8_t* db, int64_t nd, int32_t* bestIdx, uint16_t* bestDist,
                     uint16_t* secondDist);

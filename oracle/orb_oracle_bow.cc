@@ -249,4 +249,79 @@ int searchByBoW(const KeyPoint* kfKeysUn, const uint8_t* kfDesc, const uint8_t* 
     return nmatches;
 }
 
+// ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vector<MapPoint*>&), include/ORBmatcher.h:110.  The fork
+// declares it and defines it nowhere; this is the loop of upstream ORB-SLAM2 (of which the fork is a
+// copy), which differs from the keyframe-to-frame search above in three places: second-side features need a
+// good map point as well (valid2) and are given away once (vbMatched2), the distance test is the strict
+// bestDist1 < TH_LOW, and the result is indexed by the first keyframe's features.
+int searchByBoWKeyFrames(const KeyPoint* keysUn1, const uint8_t* desc1, const uint8_t* valid1, int n1,
+                         const std::map<int, std::vector<unsigned> >& feat1, const KeyPoint* keysUn2,
+                         const uint8_t* desc2, const uint8_t* valid2, int n2,
+                         const std::map<int, std::vector<unsigned> >& feat2, float nnratio, bool checkOri,
+                         int* matches12) {
+    const int TH_LOW = 50, HISTO_LENGTH = 30;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    std::vector<bool> vbMatched2((size_t)n2, false);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = HISTO_LENGTH / 360.0f;
+    int nmatches = 0;
+    auto f1it = feat1.begin();
+    auto f2it = feat2.begin();
+    while (f1it != feat1.end() && f2it != feat2.end()) {
+        if (f1it->first == f2it->first) {
+            for (size_t i1 = 0; i1 < f1it->second.size(); i1++) {
+                const size_t idx1 = f1it->second[i1];
+                if (!valid1[idx1]) continue;
+                const uint8_t* d1 = desc1 + idx1 * 32;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (size_t i2 = 0; i2 < f2it->second.size(); i2++) {
+                    const size_t idx2 = f2it->second[i2];
+                    if (vbMatched2[idx2] || !valid2[idx2]) continue;
+                    const int dist = hammingBitHack(d1, desc2 + idx2 * 32);
+                    if (dist < bestDist1) {
+                        bestDist2 = bestDist1;
+                        bestDist1 = dist;
+                        bestIdx2 = (int)idx2;
+                    } else if (dist < bestDist2) {
+                        bestDist2 = dist;
+                    }
+                }
+                if (bestDist1 < TH_LOW) {
+                    if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                        matches12[idx1] = bestIdx2;
+                        vbMatched2[(size_t)bestIdx2] = true;
+                        if (checkOri) {
+                            float rot = keysUn1[idx1].angle - keysUn2[bestIdx2].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)roundf(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back((int)idx1);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            f1it++;
+            f2it++;
+        } else if (f1it->first < f2it->first) {
+            f1it = feat1.lower_bound(f2it->first);
+        } else {
+            f2it = feat2.lower_bound(f1it->first);
+        }
+    }
+    if (checkOri) {
+        int counts[HISTO_LENGTH], ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) counts[i] = (int)rotHist[i].size();
+        computeThreeMaxima(counts, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) {
+                matches12[rotHist[i][j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
 }  // namespace orbo

@@ -190,6 +190,25 @@ int oro_search_by_projection(const float* u, const float* v, const float* radius
                               checkOri != 0, quirks);
 }
 
+int oro_search_local_map(const float* u, const float* v, const float* radius, const int* minLevel, const int* maxLevel,
+                         const uint8_t* qdesc, const uint8_t* qobs, int nq, const KeyPoint* k2, const uint8_t* d2, int n2,
+                         int imgW, int imgH, const uint8_t* occupied2, int* match2, int thHigh, float nnratio,
+                         unsigned quirks) {
+    FrameGrid F2;
+    F2.build(k2, d2, n2, imgW, imgH, bounds());
+    return searchLocalMap(u, v, radius, minLevel, maxLevel, qdesc, qobs, nq, F2, occupied2, match2, thHigh, nnratio, quirks);
+}
+
+void oro_search_best(const float* u, const float* v, const float* radius, const int* minLevel, const int* maxLevel,
+                     const uint8_t* qdesc, int nq, const KeyPoint* k2, const uint8_t* d2, int n2, int imgW, int imgH,
+                     const float* invLevelSigma2, int nlevels, double chi2Max, int th, unsigned quirks, int* bestIdx,
+                     int* bestDist) {
+    FrameGrid F2;
+    F2.build(k2, d2, n2, imgW, imgH, bounds());
+    searchBest(u, v, radius, minLevel, maxLevel, qdesc, nq, F2, invLevelSigma2, nlevels, chi2Max, th, quirks, bestIdx,
+               bestDist);
+}
+
 void oro_bf_top2(const uint8_t* q, int nq, const uint8_t* db, long long nd, int32_t* idx, uint16_t* d1, uint16_t* d2) {
     bruteForceTop2(q, nq, db, nd, idx, d1, d2);
 }
@@ -268,6 +287,14 @@ int oro_search_by_bow(const KeyPoint* kfKeysUn, const uint8_t* kfDesc, const uin
                       int* matchKF) {
     return searchByBoW(kfKeysUn, kfDesc, kfValid, fv_from_csr(kfNodes, kfOffsets, kfIdx, kfNN), fKeys, fDesc, nF,
                        fv_from_csr(fNodes, fOffsets, fIdx, fNN), nnratio, checkOri != 0, matchKF);
+}
+
+int oro_search_by_bow_keyframes(const KeyPoint* keysUn1, const uint8_t* desc1, const uint8_t* valid1, int n1,
+                                const int* nodes1, const int* offsets1, const int* idx1, int nn1, const KeyPoint* keysUn2,
+                                const uint8_t* desc2, const uint8_t* valid2, int n2, const int* nodes2, const int* offsets2,
+                                const int* idx2, int nn2, float nnratio, int checkOri, int* matches12) {
+    return searchByBoWKeyFrames(keysUn1, desc1, valid1, n1, fv_from_csr(nodes1, offsets1, idx1, nn1), keysUn2, desc2,
+                                valid2, n2, fv_from_csr(nodes2, offsets2, idx2, nn2), nnratio, checkOri != 0, matches12);
 }
 
 }  // extern "C"

@@ -341,6 +341,85 @@ int searchByProjection(const float* u, const float* v, const float* radius, cons
     return nmatches;
 }
 
+// ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th), include/ORBmatcher.h:24-39
+// (tracking of the local map).  The fork declares it with its five steps and defines it nowhere; the loop
+// is upstream ORB-SLAM2's.  Queries are the local map points that isInFrustum left in view: (u,v) =
+// (mTrackProjX, mTrackProjY), radius = r * scale factor of the predicted level, levels [predicted - 1,
+// predicted].  A keypoint that holds a map point with observations is skipped, and an accepted query
+// stores its own map point there, so later queries see it (qobs as in searchByProjection above).
+int searchLocalMap(const float* u, const float* v, const float* radius, const int* minLevel, const int* maxLevel,
+                   const uint8_t* qdesc, const uint8_t* qobs, int nq, const FrameGrid& F, const uint8_t* occupied2,
+                   int* match2, int thHigh, float nnratio, unsigned quirks) {
+    int nmatches = 0;
+    std::vector<uint8_t> occ(F.N, 0);
+    for (int i = 0; i < F.N; i++) {
+        match2[i] = -1;
+        if (occupied2) occ[i] = occupied2[i] ? 1 : 0;
+    }
+    for (int iMP = 0; iMP < nq; iMP++) {
+        // isInFrustum (upstream Frame.cc) has rejected projections outside the image bounds
+        if (u[iMP] < F.minX || u[iMP] > F.maxX || v[iMP] < F.minY || v[iMP] > F.maxY) continue;
+        const std::vector<int> vIndices = F.featuresInArea(u[iMP], v[iMP], radius[iMP], minLevel[iMP], maxLevel[iMP], quirks);
+        if (vIndices.empty()) continue;
+        const uint8_t* MPdescriptor = qdesc + (size_t)iMP * 32;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int idx : vIndices) {
+            if (occ[idx]) continue;
+            const int dist = hammingBitHack(MPdescriptor, F.desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist2 = bestDist;
+                bestDist = dist;
+                bestLevel2 = bestLevel;
+                bestLevel = F.keys[idx].octave;
+                bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = F.keys[idx].octave;
+                bestDist2 = dist;
+            }
+        }
+        // the ratio applies only when best and second best lie on the same scale level
+        if (bestDist <= thHigh) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            match2[bestIdx] = iMP;
+            occ[bestIdx] = qobs ? (qobs[iMP] ? 1 : 0) : 1;
+            nmatches++;
+        }
+    }
+    return nmatches;
+}
+
+// Candidate loop of ORBmatcher::Fuse (include/ORBmatcher.h:163-184, both overloads) and of
+// ORBmatcher::SearchBySim3 (:146-160), declared by the fork and defined nowhere in it; upstream ORB-SLAM2's
+// loops.  Every query on its own: window, level range [predicted - 1, predicted], for the first Fuse
+// overload the monocular reprojection gate (squared error times the level's inverse sigma^2 above 5.99
+// rejects the candidate), smallest distance, first candidate among equals; kept when <= th.
+void searchBest(const float* u, const float* v, const float* radius, const int* minLevel, const int* maxLevel,
+                const uint8_t* qdesc, int nq, const FrameGrid& F, const float* invLevelSigma2, int nlevels,
+                double chi2Max, int th, unsigned quirks, int* bestIdxOut, int* bestDistOut) {
+    for (int i = 0; i < nq; i++) {
+        const std::vector<int> vIndices = F.featuresInArea(u[i], v[i], radius[i], minLevel[i], maxLevel[i], quirks);
+        int bestDist = 256, bestIdx = -1;
+        for (int idx : vIndices) {
+            const KeyPoint& kp = F.keys[idx];
+            if (invLevelSigma2) {
+                const int kpLevel = kp.octave;
+                if (kpLevel < 0 || kpLevel >= nlevels) continue;  // the reference would read outside mvInvLevelSigma2
+                const float ex = u[i] - kp.x;
+                const float ey = v[i] - kp.y;
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * invLevelSigma2[kpLevel] > chi2Max) continue;
+            }
+            const int dist = hammingBitHack(qdesc + (size_t)i * 32, F.desc + (size_t)idx * 32);
+            if (dist < bestDist) {
+                bestDist = dist;
+                bestIdx = idx;
+            }
+        }
+        bestIdxOut[i] = (bestDist <= th) ? bestIdx : -1;
+        bestDistOut[i] = bestDist;
+    }
+}
+
 // Dense scan with the best / second-best rule of src/ORBmatcher.cc:53-76.
 void bruteForceTop2(const uint8_t* q, int nq, const uint8_t* db, int64_t nd, int32_t* bestIdx, uint16_t* bestDist,
                     uint16_t* secondDist) {

@@ -34,6 +34,7 @@ EXPORTS = [
     "orb_undistort_keypoints", "orb_undistort_keypoints_device", "orb_compute_image_bounds", "orb_set_image_bounds",
     "orb_voc_load_text", "orb_voc_create", "orb_voc_destroy", "orb_voc_info", "orb_voc_transform",
     "orb_voc_transform_device", "orb_voc_bow", "orb_bow_score_l1", "orb_match_bow",
+    "orb_match_local_map", "orb_match_best", "orb_match_bow_keyframes",
 ]
 
 
@@ -242,6 +243,42 @@ class Context:
                                          _p(match2), th_high, int(check_ori), C.byref(nm)))
         return nm.value, match2[: len(k2)]
 
+    def match_local_map(self, u, v, radius, min_level, max_level, qdesc, qobs, k2, d2, img_w, img_h, occupied2=None,
+                        th_high=100, nnratio=0.8):
+        """Search loop of ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)
+        (include/ORBmatcher.h:24-39).  Returns (nmatches, match2[n2])."""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        i32 = lambda a: np.ascontiguousarray(a, np.int32)
+        u8 = lambda a: None if a is None else np.ascontiguousarray(a, np.uint8)
+        u, v, radius = f32(u), f32(v), f32(radius)
+        min_level, max_level = i32(min_level), i32(max_level)
+        qdesc, d2, qobs, occ = u8(qdesc), u8(d2), u8(qobs), u8(occupied2)
+        k2 = np.ascontiguousarray(k2, KP_DTYPE)
+        match2 = np.zeros(max(len(k2), 1), np.int32)
+        nm = C.c_int(0)
+        _check(lib().orb_match_local_map(self.h, _p(u), _p(v), _p(radius), _p(min_level), _p(max_level), _p(qdesc),
+                                         _p(qobs), len(u), _p(k2), _p(d2), len(k2), img_w, img_h, _p(occ), _p(match2),
+                                         th_high, C.c_float(nnratio), C.byref(nm)))
+        return nm.value, match2[: len(k2)]
+
+    def match_best(self, u, v, radius, min_level, max_level, qdesc, k2, d2, img_w, img_h, inv_level_sigma2=None,
+                   chi2_max=5.99, th=50):
+        """Candidate loop of ORBmatcher::Fuse / SearchBySim3 (include/ORBmatcher.h:146-184): the best keypoint
+        of every query on its own.  Returns (best_idx, best_dist) int32 arrays."""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        i32 = lambda a: np.ascontiguousarray(a, np.int32)
+        u, v, radius = f32(u), f32(v), f32(radius)
+        min_level, max_level = i32(min_level), i32(max_level)
+        qdesc, d2 = np.ascontiguousarray(qdesc, np.uint8), np.ascontiguousarray(d2, np.uint8)
+        k2 = np.ascontiguousarray(k2, KP_DTYPE)
+        sig = None if inv_level_sigma2 is None else f32(inv_level_sigma2)
+        idx = np.zeros(max(len(u), 1), np.int32)
+        dist = np.zeros(max(len(u), 1), np.int32)
+        _check(lib().orb_match_best(self.h, _p(u), _p(v), _p(radius), _p(min_level), _p(max_level), _p(qdesc), len(u),
+                                    _p(k2), _p(d2), len(k2), img_w, img_h, _p(sig), 0 if sig is None else len(sig),
+                                    C.c_double(chi2_max), th, _p(idx), _p(dist)))
+        return idx[: len(u)], dist[: len(u)]
+
     def undistort_keypoints(self, kps, K, dist):
         """Frame::UndistortKeyPoints; K = (fx, fy, cx, cy), dist = (k1, k2, p1, p2, k3)."""
         kps = np.ascontiguousarray(kps, KP_DTYPE)
@@ -302,6 +339,22 @@ class Context:
                                    _p(fd), len(fk), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]), C.c_float(nnratio),
                                    int(check_ori), _p(match), C.byref(nm)))
         return nm.value, match[: len(fk)]
+
+    def match_bow_keyframes(self, keys_un1, desc1, valid1, fv1, keys_un2, desc2, valid2, fv2, nnratio=0.75, check_ori=True):
+        """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, ...) (include/ORBmatcher.h:110).  Returns
+        (nmatches, matches12[n1])."""
+        k1 = np.ascontiguousarray(keys_un1, KP_DTYPE)
+        k2 = np.ascontiguousarray(keys_un2, KP_DTYPE)
+        d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+        v1, v2 = np.ascontiguousarray(valid1, np.uint8), np.ascontiguousarray(valid2, np.uint8)
+        a = [np.ascontiguousarray(x, np.int32) for x in fv1]
+        b = [np.ascontiguousarray(x, np.int32) for x in fv2]
+        match = np.full(max(len(k1), 1), -1, np.int32)
+        nm = C.c_int(0)
+        _check(lib().orb_match_bow_keyframes(self.h, _p(k1), _p(d1), _p(v1), len(k1), _p(a[0]), _p(a[1]), _p(a[2]),
+                                             len(a[0]), _p(k2), _p(d2), _p(v2), len(k2), _p(b[0]), _p(b[1]), _p(b[2]),
+                                             len(b[0]), C.c_float(nnratio), int(check_ori), _p(match), C.byref(nm)))
+        return nm.value, match[: len(k1)]
 
 
 class BruteForce:

@@ -426,7 +426,8 @@ __global__ __launch_bounds__(256) void k_bow_match(const BowSegment* __restrict_
                                                    const int* __restrict__ kfIdx, const uint8_t* __restrict__ kfDesc,
                                                    const uint8_t* __restrict__ kfValid, const float* __restrict__ kfAngle,
                                                    const int* __restrict__ fIdx, const uint8_t* __restrict__ fDesc,
-                                                   const float* __restrict__ fAngle, float nnratio,
+                                                   const float* __restrict__ fAngle,
+                                                   const uint8_t* __restrict__ fValid, int thLow, float nnratio,
                                                    int* __restrict__ matchKF, int* __restrict__ binOf) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int s = blockIdx.x * 4 + wave;
@@ -443,6 +444,7 @@ __global__ __launch_bounds__(256) void k_bow_match(const BowSegment* __restrict_
             const bool taken = t < 64 ? ((taken0 >> t) & 1ull) : ((taken1 >> (t - 64)) & 1ull);
             if (taken) continue;  // :188
             const int rf = fIdx[sg.fStart + p];
+            if (fValid && !fValid[rf]) continue;  // keyframe-to-keyframe form: the second side needs a map point too
             const uint32_t key = ((uint32_t)hamming_rows(a0, a1, fDesc + (size_t)rf * 32) << 16) | (uint32_t)p;
             if (key < k1) {
                 k2 = k1;
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(256) void k_bow_match(const BowSegment* __restrict_
         // the reference starts both distances at 256 (:180-182); a distance of 256 never replaces them
         const int bestDist1 = k1 == 0xffffffffu ? 256 : (int)(k1 >> 16);
         const int bestDist2 = k2 == 0xffffffffu ? 256 : (int)(k2 >> 16);
-        if (bestDist1 <= M_TH_LOW && (float)bestDist1 < __fmul_rn(nnratio, (float)bestDist2)) {
+        if (bestDist1 <= thLow && (float)bestDist1 < __fmul_rn(nnratio, (float)bestDist2)) {
             const int p = (int)(k1 & 0xffffu);
             if (lane == (p & 63)) {
                 const int t = p >> 6;
@@ -546,11 +548,13 @@ static int check_feature_vector(const char* who, const int* node, const int* off
     return ORB_OK;
 }
 
-extern "C" int orb_match_bow(orb_ctx* c, const orb_keypoint* kf_keys_un, const uint8_t* kf_desc, const uint8_t* kf_valid,
-                             int nkf, const int* kf_fv_node, const int* kf_fv_offsets, const int* kf_fv_index, int kf_nfv,
-                             const orb_keypoint* f_keys, const uint8_t* f_desc, int nf, const int* f_fv_node,
-                             const int* f_fv_offsets, const int* f_fv_index, int f_nfv, float nnratio, int check_ori,
-                             int* match_kf, int* nmatches) {
+// f_valid == NULL, th_low = TH_LOW: SearchByBoW(KeyFrame*, Frame&, ..).  f_valid given, th_low = TH_LOW - 1:
+// the keyframe-to-keyframe overload, whose test is the strict bestDist1 < TH_LOW.
+static int match_bow(orb_ctx* c, const orb_keypoint* kf_keys_un, const uint8_t* kf_desc, const uint8_t* kf_valid,
+                     int nkf, const int* kf_fv_node, const int* kf_fv_offsets, const int* kf_fv_index, int kf_nfv,
+                     const orb_keypoint* f_keys, const uint8_t* f_desc, const uint8_t* f_valid, int nf,
+                     const int* f_fv_node, const int* f_fv_offsets, const int* f_fv_index, int f_nfv, int th_low,
+                     float nnratio, int check_ori, int* match_kf, int* nmatches) {
     if (!c || !nmatches || nkf < 0 || nf < 0 || (nf > 0 && (!match_kf || !f_desc || !f_keys)) ||
         (nkf > 0 && (!kf_desc || !kf_valid || !kf_keys_un))) {
         orb_set_error("orb_match_bow: bad arguments");
@@ -607,6 +611,7 @@ extern "C" int orb_match_bow(orb_ctx* c, const orb_keypoint* kf_keys_un, const u
     const size_t oKfValid = o;  o += align256((size_t)nkf);
     const size_t oKfAng = o;    o += align256((size_t)nkf * 4);
     const size_t oFAng = o;     o += align256((size_t)nf * 4);
+    const size_t oFValid = o;   o += align256((size_t)nf);
     const size_t inBytes = o;
     const size_t oMatch = o;    o += align256((size_t)nf * 4);
     const size_t oCount = o;    o += 256;
@@ -623,12 +628,14 @@ extern "C" int orb_match_bow(orb_ctx* c, const orb_keypoint* kf_keys_un, const u
     memcpy(h + oKfValid, kf_valid, (size_t)nkf);
     for (int i = 0; i < nkf; i++) ((float*)(h + oKfAng))[i] = kf_keys_un[i].angle;
     for (int j = 0; j < nf; j++) ((float*)(h + oFAng))[j] = f_keys[j].angle;
+    if (f_valid) memcpy(h + oFValid, f_valid, (size_t)nf);
     HIP_TRY(hipMemcpyAsync(d, h, inBytes, hipMemcpyHostToDevice, st->stream));
     HIP_TRY(hipMemsetAsync(d + oMatch, 0xff, (size_t)nf * 4, st->stream));
     hipLaunchKernelGGL(k_bow_match, dim3((nsegs + 3) / 4), dim3(256), 0, st->stream, (const BowSegment*)(d + oSeg), nsegs,
                        (const int*)(d + oKfIdx), d + oKfDesc, d + oKfValid, (const float*)(d + oKfAng),
-                       (const int*)(d + oFIdx), d + oFDesc, (const float*)(d + oFAng), nnratio, (int*)(d + oMatch),
-                       (int*)(d + oBin));
+                       (const int*)(d + oFIdx), d + oFDesc, (const float*)(d + oFAng),
+                       f_valid ? (const uint8_t*)(d + oFValid) : (const uint8_t*)nullptr, th_low, nnratio,
+                       (int*)(d + oMatch), (int*)(d + oBin));
     hipLaunchKernelGGL(k_bow_finish, dim3(1), dim3(256), 0, st->stream, nf, check_ori ? 1 : 0, (int*)(d + oMatch),
                        (const int*)(d + oBin), (int*)(d + oCount));
     hipError_t e = hipGetLastError();
@@ -640,5 +647,38 @@ extern "C" int orb_match_bow(orb_ctx* c, const orb_keypoint* kf_keys_un, const u
     HIP_TRY(hipStreamSynchronize(st->stream));
     memcpy(match_kf, h + oMatch, (size_t)nf * 4);
     *nmatches = *(const int*)(h + oCount);
+    return ORB_OK;
+}
+
+extern "C" int orb_match_bow(orb_ctx* c, const orb_keypoint* kf_keys_un, const uint8_t* kf_desc, const uint8_t* kf_valid,
+                             int nkf, const int* kf_fv_node, const int* kf_fv_offsets, const int* kf_fv_index, int kf_nfv,
+                             const orb_keypoint* f_keys, const uint8_t* f_desc, int nf, const int* f_fv_node,
+                             const int* f_fv_offsets, const int* f_fv_index, int f_nfv, float nnratio, int check_ori,
+                             int* match_kf, int* nmatches) {
+    return match_bow(c, kf_keys_un, kf_desc, kf_valid, nkf, kf_fv_node, kf_fv_offsets, kf_fv_index, kf_nfv, f_keys, f_desc,
+                     nullptr, nf, f_fv_node, f_fv_offsets, f_fv_index, f_nfv, M_TH_LOW, nnratio, check_ori, match_kf,
+                     nmatches);
+}
+
+extern "C" int orb_match_bow_keyframes(orb_ctx* c, const orb_keypoint* keys_un1, const uint8_t* desc1,
+                                       const uint8_t* valid1, int n1, const int* fv_node1, const int* fv_offsets1,
+                                       const int* fv_index1, int nfv1, const orb_keypoint* keys_un2, const uint8_t* desc2,
+                                       const uint8_t* valid2, int n2, const int* fv_node2, const int* fv_offsets2,
+                                       const int* fv_index2, int nfv2, float nnratio, int check_ori, int* matches12,
+                                       int* nmatches) {
+    if (!nmatches || n1 < 0 || n2 < 0 || (n1 > 0 && !matches12) || (n2 > 0 && !valid2)) {
+        orb_set_error("orb_match_bow_keyframes: bad arguments");
+        return ORB_ERR_INVALID;
+    }
+    // A feature of the second keyframe is given away at most once and a feature of the first takes at
+    // most one: the match list by second-side feature is the inverse of vpMatches12.
+    std::vector<int> by2((size_t)(n2 > 0 ? n2 : 1), -1);
+    const int rc = match_bow(c, keys_un1, desc1, valid1, n1, fv_node1, fv_offsets1, fv_index1, nfv1, keys_un2, desc2,
+                             valid2, n2, fv_node2, fv_offsets2, fv_index2, nfv2, M_TH_LOW - 1, nnratio, check_ori,
+                             by2.data(), nmatches);
+    if (rc) return rc;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    for (int j = 0; j < n2; j++)
+        if (by2[(size_t)j] >= 0) matches12[by2[(size_t)j]] = j;
     return ORB_OK;
 }

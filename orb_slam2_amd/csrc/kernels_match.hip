@@ -283,7 +283,65 @@ __global__ __launch_bounds__(256) void k_match_lists(const orb_keypoint* __restr
     if (lane == 0) counts[q] = n < B.capQ ? n : B.capQ;  // n <= keypoints in the grid <= capQ
 }
 
-// Kernel 3.
+// Best candidate of every query on its own, for the searches in which one query's outcome does not
+// change what the next may take: the candidate loops of ORBmatcher::Fuse (both overloads,
+// include/ORBmatcher.h:163-184) and ORBmatcher::SearchBySim3 (:146-160).  One wavefront per query:
+// window query, level range, optionally the reprojection-error gate of Fuse (squared pixel error
+// times the candidate level's inverse sigma^2 above chi2Max rejects), smallest distance, first
+// candidate in window order among equals; kept when the distance is at most `th`.
+__global__ __launch_bounds__(256) void k_match_best(const float* __restrict__ u, const float* __restrict__ v,
+                                                    const float* __restrict__ radius, const int* __restrict__ minLevel,
+                                                    const int* __restrict__ maxLevel, const uint8_t* __restrict__ qdesc,
+                                                    int nq, const uint8_t* __restrict__ d2,
+                                                    const float* __restrict__ invSigma2, int nSigma, double chi2Max, int th,
+                                                    GridGeom G, unsigned quirks, MatchBuffers B,
+                                                    int* __restrict__ bestIdx, int* __restrict__ bestDist) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (q >= nq) return;
+    const float x = u[q], y = v[q], r = radius[q];
+    const int lmin = minLevel[q], lmax = maxLevel[q];
+    const bool excl = (quirks & ORB_Q_GRID_EXCLUSIVE) != 0, circ = (quirks & ORB_Q_WINDOW_CIRCULAR) != 0;
+    const Window w = window_cells(x, y, r, G, excl);
+    uint32_t best = 0xFFFFFFFFu;
+    if (w.x1 > w.x0 && w.y1 > w.y0) {
+        const int lo = B.cellStart[w.x0 * ORB_GRID_ROWS + w.y0];
+        const int hi = B.cellStart[(w.x1 - 1) * ORB_GRID_ROWS + w.y1];
+        const uint4 a0 = ((const uint4*)(qdesc + (int64_t)q * 32))[0], a1 = ((const uint4*)(qdesc + (int64_t)q * 32))[1];
+        const bool checkLevels = lmin >= 0 || lmax >= 0;
+        const float r2 = __fmul_rn(r, r);
+        for (int p = lo + lane; p < hi; p += 64) {
+            const uint32_t key = B.gSorted[p];
+            const int iy = (int)(key >> 16) % ORB_GRID_ROWS;
+            if (iy < w.y0 || iy >= w.y1) continue;
+            const int o = B.gOct[p];
+            if (checkLevels && (o < lmin || (lmax >= 0 && o > lmax))) continue;
+            const float2 c = B.gXY[p];
+            const float dx = __fsub_rn(c.x, x), dy = __fsub_rn(c.y, y);
+            const float e2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+            if (circ ? !(e2 < r2) : !(fabsf(dx) < r && fabsf(dy) < r)) continue;
+            if (invSigma2) {
+                if (o >= nSigma) continue;  // no sigma for that level
+                if ((double)__fmul_rn(e2, invSigma2[o]) > chi2Max) continue;
+            }
+            const uint32_t dist = (uint32_t)hamming_rows(a0, a1, d2 + (int64_t)(key & 0xFFFFu) * 32);
+            best = min(best, (dist << 16) | (uint32_t)p);
+        }
+    }
+    best = wave_min_u32(best);
+    if (lane == 0) {
+        const int dist = best == 0xFFFFFFFFu ? 256 : (int)(best >> 16);  // the searches start from 256 with a strict '<'
+        const bool ok = dist < 256 && dist <= th;
+        bestIdx[q] = ok ? (int)(B.gSorted[best & 0xFFFFu] & 0xFFFFu) : -1;
+        bestDist[q] = dist;
+    }
+}
+
+// Kernel 3.  MODE 0: window search (SearchForInitialization).  MODE 1: projected search, best
+// candidate only (SearchByProjection(Frame&, const Frame&, ..)).  MODE 2: projected search with the
+// best / second-best rule of the local-map search (SearchByProjection(Frame&, const vector<MapPoint*>&,
+// th), include/ORBmatcher.h:24-39): the ratio test applies only when both candidates lie on the same
+// pyramid level.
 struct ResolveLds {
     uint32_t tile[2][64][128];      // first 128 list entries of 64 queries, double buffered
     int metaI1[2][64];              // the 64 queries of a chunk: index, list length, "map point has observations"
@@ -291,15 +349,16 @@ struct ResolveLds {
     int metaObs[2][64];
     uint16_t idx[M_MAXKP];          // keypoint index by sorted position
     // State of the searched frame's keypoints, by sorted position (the lists name positions).  Low half:
-    // vMatchedDistance (0xFFFF = INT_MAX) for the window search, occupancy flag for the projected one;
-    // high half: vnMatches21 (window search).
+    // vMatchedDistance (0xFFFF = INT_MAX) for the window search; occupancy flag in bits 0-7 and (MODE 2)
+    // the keypoint's octave in bits 8-15 for the projected ones.  High half: owner (vnMatches21 / the
+    // query whose map point the keypoint holds).
     uint32_t so[M_MAXKP];
     int hist[ORB_HISTO];
     int wcount[4];
     int nmatches;
 };
 
-template <bool PROJECTED>
+template <int MODE>
 __global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __restrict__ k1all,
                                                        const int* __restrict__ n1s, int nqConst, int stride1,
                                                        const orb_keypoint* __restrict__ k2all,
@@ -311,6 +370,7 @@ __global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __res
                                                        float nnratio, int thHigh, int checkOri, MatchBuffers B,
                                                        int* __restrict__ nmatchesOut, int* __restrict__ error) {
     __shared__ ResolveLds S;
+    constexpr bool PROJECTED = MODE != 0;
     const int pair = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const orb_keypoint* k1 = PROJECTED ? nullptr : k1all + (int64_t)pair * stride1;
     const orb_keypoint* k2 = k2all + (int64_t)pair * stride2;
@@ -342,7 +402,9 @@ __global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __res
     for (int p = t; p < nIn; p += 256) {
         const int i2 = (int)(gS[p] & 0xFFFFu);
         S.idx[p] = (uint16_t)i2;
-        if (PROJECTED) S.so[p] = 0xFFFF0000u | (occupied2 ? occupied2[i2] : 0);  // owner -1
+        if (PROJECTED)  // owner -1
+            S.so[p] = 0xFFFF0000u | (MODE == 2 ? (uint32_t)B.gOct[(int64_t)pair * stride2 + p] << 8 : 0u) |
+                      (occupied2 && occupied2[i2] ? 1u : 0u);
         else S.so[p] = 0xFFFFFFFFu;                                            // distance INT_MAX, owner -1
     }
     if (t < ORB_HISTO) S.hist[t] = 0;
@@ -427,7 +489,7 @@ __global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __res
                 uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
                 auto consider = [&](uint32_t e) {
                     const uint32_t st = S.so[e & 0xFFFFu] & 0xFFFFu;
-                    const bool skip = PROJECTED ? (st != 0) : (st <= (e >> 16));  // :345-347 / :63-64
+                    const bool skip = PROJECTED ? ((st & 0xFFu) != 0) : (st <= (e >> 16));  // :345-347 / :63-64
                     if (!skip) {
                         k2 = min(k2, max(k1, e));
                         k1 = min(k1, e);
@@ -436,7 +498,7 @@ __global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __res
                 if (lane < cnt) consider(e0);
                 if (lane + 64 < cnt) consider(e1);
                 for (int c = lane + 128; c < cnt; c += 64) consider(lists[(int64_t)i1 * B.capQ + c]);
-                if (PROJECTED) k1 = wave_min_u32(k1);
+                if (MODE == 1) k1 = wave_min_u32(k1);
                 else wave_top2_u32(k1, k2);
                 e0 = n0;
                 e1 = n1;
@@ -444,8 +506,16 @@ __global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __res
                 const int bestDist = (int)(k1 >> 16);
                 const int bestPos = (int)(k1 & 0xFFFFu);
                 bool accept;
-                if (PROJECTED) {
+                if (MODE == 1) {
                     accept = bestDist < 256 && bestDist <= thHigh;  // bestDist starts at 256 with strict '<', :339,357,363
+                } else if (MODE == 2) {
+                    // both distances start at 256 and both levels at -1; a candidate at distance 256 replaces neither
+                    accept = bestDist < 256 && bestDist <= thHigh;
+                    const int dist2 = (k2 == 0xFFFFFFFFu) ? 256 : (int)(k2 >> 16);
+                    if (accept && dist2 < 256) {
+                        const uint32_t lv1 = (S.so[bestPos] >> 8) & 0xFFu, lv2 = (S.so[k2 & 0xFFFFu] >> 8) & 0xFFu;
+                        if (lv1 == lv2 && (float)bestDist > __fmul_rn(nnratio, (float)dist2)) accept = false;
+                    }
                 } else {
                     // second best = smallest distance among everything but the winning entry
                     const float bestDist2 = (k2 == 0xFFFFFFFFu) ? (float)INT_MAX : (float)(int)(k2 >> 16);
@@ -456,7 +526,9 @@ __global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __res
                     // the map-point assignment follow from it after the loop), the acceptance in a register.
                     const int bestIdx2 = S.idx[bestPos];
                     if (lane == qq) accL = bestIdx2;
-                    if (lane == 0) S.so[bestPos] = (PROJECTED ? (uint32_t)obs : (uint32_t)bestDist) | ((uint32_t)i1 << 16);
+                    if (lane == 0)
+                        S.so[bestPos] = (PROJECTED ? ((S.so[bestPos] & 0xFF00u) | (obs ? 1u : 0u)) : (uint32_t)bestDist) |
+                                        ((uint32_t)i1 << 16);
                     nmatches++;
                     wave_lds_order();
                 }
@@ -702,7 +774,7 @@ extern "C" int orb_match_window_batch_device(orb_ctx* c, int npairs, const orb_k
                        stride1, (const float*)d_prev_xy, (float)window, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const int*)nullptr, (const int*)nullptr, d_d2, stride2, G, orb_ctx_quirks(c), B);
     if ((rc = check_match_launch())) return rc;
-    hipLaunchKernelGGL(k_match_resolve<false>, dim3(npairs), dim3(256), 0, st, d_k1, d_n1, 0, stride1, d_k2, d_n2, 0,
+    hipLaunchKernelGGL(k_match_resolve<0>, dim3(npairs), dim3(256), 0, st, d_k1, d_n1, 0, stride1, d_k2, d_n2, 0,
                        stride2, d_prev_xy, d_matches12, (uint8_t*)s->binOf, (const float*)nullptr,
                        (const uint8_t*)nullptr, (const uint8_t*)nullptr, (int*)nullptr, nnratio, 0, check_ori, B,
                        d_nmatches, (int*)s->err);
@@ -799,14 +871,16 @@ extern "C" int orb_match_window(orb_ctx* c, const orb_keypoint* k1, const uint8_
     return ORB_OK;
 }
 
-extern "C" int orb_match_projected(orb_ctx* c, const float* u, const float* v, const float* radius,
-                                   const int* min_level, const int* max_level, const float* qangle,
-                                   const uint8_t* qdesc, const uint8_t* qobs, int nq, const orb_keypoint* k2,
-                                   const uint8_t* d2, int n2, int img_w, int img_h, const uint8_t* occupied2,
-                                   int* match2, int th_high, int check_ori, int* nmatches) {
+// mode 1: best candidate only, rotation check on request; mode 2: local-map rule (no rotation check).
+static int match_projected(orb_ctx* c, int mode, const float* u, const float* v, const float* radius,
+                           const int* min_level, const int* max_level, const float* qangle, const uint8_t* qdesc,
+                           const uint8_t* qobs, int nq, const orb_keypoint* k2, const uint8_t* d2, int n2, int img_w,
+                           int img_h, const uint8_t* occupied2, int* match2, int th_high, float nnratio, int check_ori,
+                           int* nmatches) {
     if (!c || nq < 0 || n2 < 0 || !nmatches || (n2 > 0 && (!k2 || !d2 || !match2)) ||
-        (nq > 0 && (!u || !v || !radius || !min_level || !max_level || !qangle || !qdesc)) || img_w < 1 || img_h < 1) {
-        orb_set_error("orb_match_projected: bad arguments");
+        (nq > 0 && (!u || !v || !radius || !min_level || !max_level || (check_ori && !qangle) || !qdesc)) || img_w < 1 ||
+        img_h < 1) {
+        orb_set_error("projected matcher: bad arguments");
         return ORB_ERR_INVALID;
     }
     *nmatches = 0;
@@ -838,7 +912,7 @@ extern "C" int orb_match_projected(orb_ctx* c, const float* u, const float* v, c
     memcpy(h + oR, radius, (size_t)nq * 4);
     memcpy(h + oL0, min_level, (size_t)nq * 4);
     memcpy(h + oL1, max_level, (size_t)nq * 4);
-    memcpy(h + oA, qangle, (size_t)nq * 4);
+    if (qangle) memcpy(h + oA, qangle, (size_t)nq * 4);
     memcpy(h + oQ, qdesc, (size_t)nq * 32);
     if (qobs) memcpy(h + oObs, qobs, (size_t)nq);
     memcpy(h + oK2, k2, (size_t)n2 * sizeof(orb_keypoint));
@@ -855,11 +929,11 @@ extern "C" int orb_match_projected(orb_ctx* c, const float* u, const float* v, c
                        (const float*)(d + oU), (const float*)(d + oV), (const float*)(d + oR), (const int*)(d + oL0),
                        (const int*)(d + oL1), (const uint8_t*)(d + oD2), n2, G, orb_ctx_quirks(c), B);
     if ((rc = check_match_launch())) return rc;
-    hipLaunchKernelGGL(k_match_resolve<true>, dim3(1), dim3(256), 0, st, (const orb_keypoint*)nullptr,
-                       (const int*)nullptr, nq, nq, (const orb_keypoint*)(d + oK2), (const int*)nullptr, n2, n2,
-                       (float*)nullptr, (int*)nullptr, (uint8_t*)s->binOf, (const float*)(d + oA),
-                       qobs ? (const uint8_t*)(d + oObs) : (const uint8_t*)nullptr,
-                       occupied2 ? (const uint8_t*)(d + oOcc) : (const uint8_t*)nullptr, (int*)(d + oM), 0.f, th_high,
+    hipLaunchKernelGGL(mode == 2 ? k_match_resolve<2> : k_match_resolve<1>, dim3(1), dim3(256), 0, st,
+                       (const orb_keypoint*)nullptr, (const int*)nullptr, nq, nq, (const orb_keypoint*)(d + oK2),
+                       (const int*)nullptr, n2, n2, (float*)nullptr, (int*)nullptr, (uint8_t*)s->binOf,
+                       (const float*)(d + oA), qobs ? (const uint8_t*)(d + oObs) : (const uint8_t*)nullptr,
+                       occupied2 ? (const uint8_t*)(d + oOcc) : (const uint8_t*)nullptr, (int*)(d + oM), nnratio, th_high,
                        check_ori, B, (int*)(d + oNm), (int*)s->err);
     if ((rc = check_match_launch())) return rc;
     HIP_TRY(hipMemcpyAsync(d + oErr, s->err, 4, hipMemcpyDeviceToDevice, st));
@@ -868,5 +942,92 @@ extern "C" int orb_match_projected(orb_ctx* c, const float* u, const float* v, c
     if ((rc = match_error((const int*)(h + oErr), s, "projected matcher"))) return rc;
     memcpy(match2, h + oM, (size_t)n2 * 4);
     memcpy(nmatches, h + oNm, 4);
+    return ORB_OK;
+}
+
+extern "C" int orb_match_projected(orb_ctx* c, const float* u, const float* v, const float* radius,
+                                   const int* min_level, const int* max_level, const float* qangle,
+                                   const uint8_t* qdesc, const uint8_t* qobs, int nq, const orb_keypoint* k2,
+                                   const uint8_t* d2, int n2, int img_w, int img_h, const uint8_t* occupied2,
+                                   int* match2, int th_high, int check_ori, int* nmatches) {
+    if (nq > 0 && !qangle) {
+        orb_set_error("orb_match_projected: bad arguments");
+        return ORB_ERR_INVALID;
+    }
+    return match_projected(c, 1, u, v, radius, min_level, max_level, qangle, qdesc, qobs, nq, k2, d2, n2, img_w, img_h,
+                           occupied2, match2, th_high, 0.f, check_ori, nmatches);
+}
+
+extern "C" int orb_match_local_map(orb_ctx* c, const float* u, const float* v, const float* radius,
+                                   const int* min_level, const int* max_level, const uint8_t* qdesc,
+                                   const uint8_t* qobs, int nq, const orb_keypoint* k2, const uint8_t* d2, int n2,
+                                   int img_w, int img_h, const uint8_t* occupied2, int* match2, int th_high,
+                                   float nnratio, int* nmatches) {
+    return match_projected(c, 2, u, v, radius, min_level, max_level, nullptr, qdesc, qobs, nq, k2, d2, n2, img_w, img_h,
+                           occupied2, match2, th_high, nnratio, 0, nmatches);
+}
+
+extern "C" int orb_match_best(orb_ctx* c, const float* u, const float* v, const float* radius, const int* min_level,
+                              const int* max_level, const uint8_t* qdesc, int nq, const orb_keypoint* k2,
+                              const uint8_t* d2, int n2, int img_w, int img_h, const float* inv_level_sigma2,
+                              int nlevels, double chi2_max, int th, int* best_idx, int* best_dist) {
+    if (!c || nq < 0 || n2 < 0 || (n2 > 0 && (!k2 || !d2)) || img_w < 1 || img_h < 1 ||
+        (nq > 0 && (!u || !v || !radius || !min_level || !max_level || !qdesc || !best_idx)) ||
+        (inv_level_sigma2 && (nlevels < 1 || nlevels > 255))) {
+        orb_set_error("orb_match_best: bad arguments");
+        return ORB_ERR_INVALID;
+    }
+    if (n2 > M_MAXKP) {
+        orb_set_error("orb_match_best handles at most %d keypoints in the searched frame", M_MAXKP);
+        return ORB_ERR_UNSUPPORTED;
+    }
+    if (nq == 0) return ORB_OK;
+    if (n2 == 0) {
+        for (int i = 0; i < nq; i++) {
+            best_idx[i] = -1;
+            if (best_dist) best_dist[i] = 256;
+        }
+        return ORB_OK;
+    }
+    HIP_TRY(hipSetDevice(orb_ctx_device(c)));
+    MatchState* s = nullptr;
+    MatchBuffers B;
+    int rc = match_buffers(c, 1, 1, n2, &s, &B);  // the grid arrays; no candidate lists are written
+    if (rc) return rc;
+    const int ns = inv_level_sigma2 ? nlevels : 0;
+    Block L;
+    const size_t oU = L.add((size_t)nq * 4), oV = L.add((size_t)nq * 4), oR = L.add((size_t)nq * 4);
+    const size_t oL0 = L.add((size_t)nq * 4), oL1 = L.add((size_t)nq * 4), oQ = L.add((size_t)nq * 32);
+    const size_t oK2 = L.add((size_t)n2 * sizeof(orb_keypoint)), oD2 = L.add((size_t)n2 * 32), oSig = L.add(256 * 4);
+    const size_t oIdx = L.add((size_t)nq * 4), oDist = L.add((size_t)nq * 4), oErr = L.add(4);  // outputs
+    if ((rc = ensure_block(s, L.off))) return rc;
+    uint8_t* h = (uint8_t*)s->blockHost;
+    uint8_t* d = (uint8_t*)s->blockDev;
+    memcpy(h + oU, u, (size_t)nq * 4);
+    memcpy(h + oV, v, (size_t)nq * 4);
+    memcpy(h + oR, radius, (size_t)nq * 4);
+    memcpy(h + oL0, min_level, (size_t)nq * 4);
+    memcpy(h + oL1, max_level, (size_t)nq * 4);
+    memcpy(h + oQ, qdesc, (size_t)nq * 32);
+    memcpy(h + oK2, k2, (size_t)n2 * sizeof(orb_keypoint));
+    memcpy(h + oD2, d2, (size_t)n2 * 32);
+    if (ns) memcpy(h + oSig, inv_level_sigma2, (size_t)ns * 4);
+    hipStream_t st = nullptr;
+    HIP_TRY(hipMemcpyAsync(d, h, oIdx, hipMemcpyHostToDevice, st));
+    const GridGeom G = grid_geom(c, img_w, img_h);
+    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, st, (const orb_keypoint*)(d + oK2), (const int*)nullptr, n2, n2,
+                       G, B, (int*)s->err);
+    if ((rc = check_match_launch())) return rc;
+    hipLaunchKernelGGL(k_match_best, dim3((nq + 3) / 4), dim3(256), 0, st, (const float*)(d + oU), (const float*)(d + oV),
+                       (const float*)(d + oR), (const int*)(d + oL0), (const int*)(d + oL1), (const uint8_t*)(d + oQ), nq,
+                       (const uint8_t*)(d + oD2), ns ? (const float*)(d + oSig) : (const float*)nullptr, ns, chi2_max, th, G,
+                       orb_ctx_quirks(c), B, (int*)(d + oIdx), (int*)(d + oDist));
+    if ((rc = check_match_launch())) return rc;
+    HIP_TRY(hipMemcpyAsync(d + oErr, s->err, 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h + oIdx, d + oIdx, L.off - oIdx, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if ((rc = match_error((const int*)(h + oErr), s, "orb_match_best"))) return rc;
+    memcpy(best_idx, h + oIdx, (size_t)nq * 4);
+    if (best_dist) memcpy(best_dist, h + oDist, (size_t)nq * 4);
     return ORB_OK;
 }
