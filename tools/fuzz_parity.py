@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential test of the HIP path against the CPU oracle: random frame sizes, feature
-counts, level counts, scale factors, thresholds and presets; extraction, then both windowed searches on a
+counts, level counts, scale factors, thresholds and presets; extraction, then the windowed searches on a
 shifted copy.  usage: PYTHONPATH=. python tools/fuzz_parity.py [iterations] [seed]"""
 import sys
 
@@ -68,6 +68,22 @@ def one(it, seed):
         ng, m2g = c.match_projected(k1["x"], k1["y"], rad, lvl - 1, lvl + 1, k1["angle"], d1, qobs, k2, d2, w, h, None, 100, True)
         if ng != no or not (m2g == m2o).all():
             print(tag, "SEARCH-BY-PROJECTION MISMATCH", ng, no)
+            ok = False
+        # the overloads the reference only declares: local-map search, Fuse / SearchBySim3 candidate loop
+        occ = (splitmix64(it + 7, len(k2)) % np.uint64(7) == 0).astype(np.uint8)
+        ratio = [0.6, 0.8, 0.95][it % 3]
+        u = k1["x"] + np.float32(int(r[11] % np.uint64(7)) - 3)
+        v = k1["y"] + np.float32(int(r[12] % np.uint64(7)) - 3)
+        no, m2o = oracle.search_local_map(u, v, rad, lvl - 1, lvl, d1, qobs, k2, d2, w, h, occ, 100, ratio, preset)
+        ng, m2g = c.match_local_map(u, v, rad, lvl - 1, lvl, d1, qobs, k2, d2, w, h, occ, 100, ratio)
+        if ng != no or not (m2g == m2o).all():
+            print(tag, "LOCAL-MAP SEARCH MISMATCH", ng, no)
+            ok = False
+        sig = (1.0 / (np.float32(sf) ** np.arange(nl, dtype=np.float32)) ** 2).astype(np.float32) if it & 1 else None
+        io, do_ = oracle.search_best(u, v, rad, lvl - 1, lvl, d1, k2, d2, w, h, sig, 5.99, 50 if it & 2 else 100, preset)
+        ig, dg_ = c.match_best(u, v, rad, lvl - 1, lvl, d1, k2, d2, w, h, sig, 5.99, 50 if it & 2 else 100)
+        if not (ig == io).all() or not (dg_ == do_).all():
+            print(tag, "BEST-CANDIDATE SEARCH MISMATCH")
             ok = False
     c.close()
     if ok:
