@@ -73,11 +73,19 @@ def main():
             print("WORLD_SIZE=%d but --gpus %d: launch with torch.distributed.run --nproc-per-node N" % (world, args.gpus), file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
+    # ORB_BENCH_REHEARSE=1: several ranks share the visible GPUs and talk over gloo (a dry run of the
+    # multi-rank code path on a box with fewer GPUs than ranks; its numbers mean nothing)
+    rehearse = os.environ.get("ORB_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def barrier():
         if world > 1:
@@ -86,9 +94,13 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    def note(what):
+        if rehearse:
+            print("[rank %d] %s" % (rank, what), file=sys.stderr, flush=True)
 
     quirks = binding.ORB_QUIRKS_FORK if args.preset == "fork" else binding.ORB_QUIRKS_CANONICAL
     W, H, B = args.width, args.height, args.batch
@@ -106,10 +118,12 @@ def main():
     def step():
         ctx.extract_batch_device(d_imgs, d_kps, d_desc, d_cnt, stream)
 
+    note("context created")
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
     ctx.check_last_batch()
+    note("warm-up done")
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -119,6 +133,7 @@ def main():
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     ctx.check_last_batch()
+    note("extraction timed")
     # Per-kernel durations for the roofline: the same steps again with HIP events between the stages.
     # In that mode the library enqueues a batch as one group on one stream, so that each event pair
     # brackets exactly one stage; the timed loop above lets it overlap groups of frames on several streams.
@@ -200,14 +215,22 @@ def main():
             bf.query_packed_device(d_q, d_packed, stream)
             if timed:
                 ev1.record(stream)
-            if world > 1:
+            if world > 1 and rehearse:  # gloo: through host memory
+                torch.cuda.synchronize()
+                h_gath = torch.zeros((world, nq), dtype=torch.int64)
+                dist.all_gather_into_tensor(h_gath.view(-1), d_packed.cpu())
+                d_gath.copy_(h_gath)
+                binding.merge_packed_device(local, d_gath, world, nq, d_idx, d_b, d_s, stream)
+            elif world > 1:
                 dist.all_gather_into_tensor(d_gath.view(-1), d_packed)
                 binding.merge_packed_device(local, d_gath, world, nq, d_idx, d_b, d_s, stream)
             else:
                 binding.merge_packed_device(local, d_packed, 1, nq, d_idx, d_b, d_s, stream)
 
+        note("database ready")
         bf_step()
         torch.cuda.synchronize()
+        note("first brute-force step done")
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.bf_steps):
@@ -299,6 +322,8 @@ def main():
                        "batch_per_gpu": B, "keypoints_per_frame": round(nkp, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "parity_checked": parity, "hamming": hamming,
         }
+        if rehearse:
+            out["rehearsal"] = "ranks share GPUs, gloo collectives: not a measurement"
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
