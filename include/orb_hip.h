@@ -352,6 +352,27 @@ int orb_match_bow_keyframes(orb_ctx* ctx, const orb_keypoint* keys_un1, const ui
                             const int* fv_node2, const int* fv_offsets2, const int* fv_index2, int nfv2, float nnratio,
                             int check_ori, int* matches12, int* nmatches);
 
+/* ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo)
+ * with CheckDistEpipolarLine (include/ORBmatcher.h:133-144,196; declared only,
+ * loops as upstream ORB-SLAM2, monocular members).  free1 / free2 mark the
+ * features without a map point.  Under every common vocabulary node a free
+ * feature of keyframe 1 takes the free feature of keyframe 2 that is at most
+ * TH_LOW away, lies farther than 10 * sqrt(scale_factors[octave]) pixels from
+ * the epipole (epipole = projection of camera centre 1 into keyframe 2; NULL
+ * skips the test) and within 3.84 * level_sigma2[octave] of the epipolar line
+ * x1' F12 (F12 row-major); smallest distance, the last candidate among equals.
+ * mark_matched = 0 is upstream ORB-SLAM2, which never marks a second-side
+ * feature as used; 1 gives every second-side feature away once.  matches12[i]
+ * = feature of keyframe 2 or -1 (vMatchedPairs = the pairs (i, matches12[i])),
+ * after the rotation check when check_ori != 0. */
+int orb_match_triangulation(orb_ctx* ctx, const orb_keypoint* keys_un1, const uint8_t* desc1, const uint8_t* free1,
+                            int n1, const int* fv_node1, const int* fv_offsets1, const int* fv_index1, int nfv1,
+                            const orb_keypoint* keys_un2, const uint8_t* desc2, const uint8_t* free2, int n2,
+                            const int* fv_node2, const int* fv_offsets2, const int* fv_index2, int nfv2,
+                            const float F12[9], const float epipole[2], const float* scale_factors,
+                            const float* level_sigma2, int nlevels, int mark_matched, int check_ori, int* matches12,
+                            int* nmatches);
+
 /* ---- measurement ------------------------------------------------------------ */
 
 /* Stage timing with HIP events recorded on the launch stream around the four

@@ -406,3 +406,22 @@ def search_by_bow_keyframes(keys_un1, desc1, valid1, fv1, keys_un2, desc2, valid
                                           _p(k2), _p(d2), _p(v2), len(k2), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]),
                                           C.c_float(nnratio), int(check_ori), _p(match))
     return n, match[: len(k1)]
+
+
+def search_for_triangulation(keys_un1, desc1, free1, fv1, keys_un2, desc2, free2, fv2, F12, epipole, scale_factors,
+                             level_sigma2, mark_matched=False, check_ori=True):
+    """ORBmatcher::SearchForTriangulation (monocular): returns (nmatches, matches12[n1])."""
+    k1 = np.ascontiguousarray(keys_un1, dtype=KP_DTYPE)
+    k2 = np.ascontiguousarray(keys_un2, dtype=KP_DTYPE)
+    d1, d2, f1, f2 = _u8(desc1), _u8(desc2), _u8(free1), _u8(free2)
+    a = [np.ascontiguousarray(x, dtype=np.int32) for x in fv1]
+    b = [np.ascontiguousarray(x, dtype=np.int32) for x in fv2]
+    F = np.ascontiguousarray(F12, dtype=np.float32).reshape(9)
+    ep = None if epipole is None else np.ascontiguousarray(epipole, dtype=np.float32)
+    sc = np.ascontiguousarray(scale_factors, dtype=np.float32)
+    sg = np.ascontiguousarray(level_sigma2, dtype=np.float32)
+    match = np.full(max(len(k1), 1), -1, dtype=np.int32)
+    n = lib().oro_search_for_triangulation(_p(k1), _p(d1), _p(f1), len(k1), _p(a[0]), _p(a[1]), _p(a[2]), len(a[0]),
+                                           _p(k2), _p(d2), _p(f2), len(k2), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]),
+                                           _p(F), _p(ep), _p(sc), _p(sg), len(sc), int(mark_matched), int(check_ori), _p(match))
+    return n, match[: len(k1)]

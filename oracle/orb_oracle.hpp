@@ -171,6 +171,13 @@ int searchByBoWKeyFrames(const KeyPoint* keysUn1, const uint8_t* desc1, const ui
                          const std::map<int, std::vector<unsigned> >& feat2, float nnratio, bool checkOri,
                          int* matches12);
 
+int searchForTriangulation(const KeyPoint* keysUn1, const uint8_t* desc1, const uint8_t* free1, int n1,
+                           const std::map<int, std::vector<unsigned> >& feat1, const KeyPoint* keysUn2,
+                           const uint8_t* desc2, const uint8_t* free2, int n2,
+                           const std::map<int, std::vector<unsigned> >& feat2, const float* F12, const float* epipole,
+                           const float* scaleFactors, const float* levelSigma2, int nlevels, bool markMatched,
+                           bool checkOri, int* vMatches12);
+
 void bruteForceTop2(const uint8_t* q, int nq, const uint8_t* db, int64_t nd, int32_t* bestIdx, uint16_t* bestDist,
                     uint16_t* secondDist);
 

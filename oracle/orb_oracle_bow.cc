@@ -324,4 +324,97 @@ int searchByBoWKeyFrames(const KeyPoint* keysUn1, const uint8_t* desc1, const ui
     return nmatches;
 }
 
+// ORBmatcher::CheckDistEpipolarLine, include/ORBmatcher.h:196 (declared only; upstream ORB-SLAM2's body).
+static bool checkDistEpipolarLine(const KeyPoint& kp1, const KeyPoint& kp2, const float* F12, const float* levelSigma2) {
+    // epipolar line in second image l = x1'F12 = [a b c]
+    const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+    const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+    const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+    const float num = a * kp2.x + b * kp2.y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * levelSigma2[kp2.octave];
+}
+
+// ORBmatcher::SearchForTriangulation, include/ORBmatcher.h:133-144 (declared only; upstream ORB-SLAM2's loops for
+// the monocular case: no right-image coordinates).  free1 / free2 = "the feature has no map point".  Upstream
+// declares vbMatched2 and never sets it; markMatched turns the marking on.
+int searchForTriangulation(const KeyPoint* keysUn1, const uint8_t* desc1, const uint8_t* free1, int n1,
+                           const std::map<int, std::vector<unsigned> >& feat1, const KeyPoint* keysUn2,
+                           const uint8_t* desc2, const uint8_t* free2, int n2,
+                           const std::map<int, std::vector<unsigned> >& feat2, const float* F12, const float* epipole,
+                           const float* scaleFactors, const float* levelSigma2, int nlevels, bool markMatched,
+                           bool checkOri, int* vMatches12) {
+    const int TH_LOW = 50, HISTO_LENGTH = 30;
+    int nmatches = 0;
+    std::vector<bool> vbMatched2((size_t)n2, false);
+    for (int i = 0; i < n1; i++) vMatches12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = HISTO_LENGTH / 360.0f;  // the fork's factor, src/ORBmatcher.cc:35
+    auto f1it = feat1.begin();
+    auto f2it = feat2.begin();
+    while (f1it != feat1.end() && f2it != feat2.end()) {
+        if (f1it->first == f2it->first) {
+            for (size_t i1 = 0; i1 < f1it->second.size(); i1++) {
+                const size_t idx1 = f1it->second[i1];
+                if (!free1[idx1]) continue;  // there is already a MapPoint
+                const KeyPoint& kp1 = keysUn1[idx1];
+                const uint8_t* d1 = desc1 + idx1 * 32;
+                int bestDist = TH_LOW;
+                int bestIdx2 = -1;
+                for (size_t i2 = 0; i2 < f2it->second.size(); i2++) {
+                    const size_t idx2 = f2it->second[i2];
+                    if (vbMatched2[idx2] || !free2[idx2]) continue;
+                    const int dist = hammingBitHack(d1, desc2 + idx2 * 32);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const KeyPoint& kp2 = keysUn2[idx2];
+                    if (kp2.octave < 0 || kp2.octave >= nlevels) continue;  // the reference would read outside its tables
+                    if (epipole) {
+                        const float distex = epipole[0] - kp2.x;
+                        const float distey = epipole[1] - kp2.y;
+                        if (distex * distex + distey * distey < 100 * scaleFactors[kp2.octave]) continue;
+                    }
+                    if (checkDistEpipolarLine(kp1, kp2, F12, levelSigma2)) {
+                        bestIdx2 = (int)idx2;
+                        bestDist = dist;
+                    }
+                }
+                if (bestIdx2 >= 0) {
+                    const KeyPoint& kp2 = keysUn2[bestIdx2];
+                    vMatches12[idx1] = bestIdx2;
+                    if (markMatched) vbMatched2[(size_t)bestIdx2] = true;
+                    nmatches++;
+                    if (checkOri) {
+                        float rot = kp1.angle - kp2.angle;
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)roundf(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rotHist[bin].push_back((int)idx1);
+                    }
+                }
+            }
+            f1it++;
+            f2it++;
+        } else if (f1it->first < f2it->first) {
+            f1it = feat1.lower_bound(f2it->first);
+        } else {
+            f2it = feat2.lower_bound(f1it->first);
+        }
+    }
+    if (checkOri) {
+        int counts[HISTO_LENGTH], ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) counts[i] = (int)rotHist[i].size();
+        computeThreeMaxima(counts, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) {
+                vMatches12[rotHist[i][j]] = -1;
+                nmatches--;
+            }
+        }
+    }
+    return nmatches;
+}
+
 }  // namespace orbo

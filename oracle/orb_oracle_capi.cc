@@ -297,4 +297,15 @@ int oro_search_by_bow_keyframes(const KeyPoint* keysUn1, const uint8_t* desc1, c
                                 valid2, n2, fv_from_csr(nodes2, offsets2, idx2, nn2), nnratio, checkOri != 0, matches12);
 }
 
+int oro_search_for_triangulation(const KeyPoint* keysUn1, const uint8_t* desc1, const uint8_t* free1, int n1,
+                                 const int* nodes1, const int* offsets1, const int* idx1, int nn1, const KeyPoint* keysUn2,
+                                 const uint8_t* desc2, const uint8_t* free2, int n2, const int* nodes2, const int* offsets2,
+                                 const int* idx2, int nn2, const float* F12, const float* epipole,
+                                 const float* scaleFactors, const float* levelSigma2, int nlevels, int markMatched,
+                                 int checkOri, int* matches12) {
+    return searchForTriangulation(keysUn1, desc1, free1, n1, fv_from_csr(nodes1, offsets1, idx1, nn1), keysUn2, desc2,
+                                  free2, n2, fv_from_csr(nodes2, offsets2, idx2, nn2), F12, epipole, scaleFactors,
+                                  levelSigma2, nlevels, markMatched != 0, checkOri != 0, matches12);
+}
+
 }  // extern "C"

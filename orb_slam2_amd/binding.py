@@ -34,7 +34,7 @@ EXPORTS = [
     "orb_undistort_keypoints", "orb_undistort_keypoints_device", "orb_compute_image_bounds", "orb_set_image_bounds",
     "orb_voc_load_text", "orb_voc_create", "orb_voc_destroy", "orb_voc_info", "orb_voc_transform",
     "orb_voc_transform_device", "orb_voc_bow", "orb_bow_score_l1", "orb_match_bow",
-    "orb_match_local_map", "orb_match_best", "orb_match_bow_keyframes",
+    "orb_match_local_map", "orb_match_best", "orb_match_bow_keyframes", "orb_match_triangulation",
 ]
 
 
@@ -354,6 +354,28 @@ class Context:
         _check(lib().orb_match_bow_keyframes(self.h, _p(k1), _p(d1), _p(v1), len(k1), _p(a[0]), _p(a[1]), _p(a[2]),
                                              len(a[0]), _p(k2), _p(d2), _p(v2), len(k2), _p(b[0]), _p(b[1]), _p(b[2]),
                                              len(b[0]), C.c_float(nnratio), int(check_ori), _p(match), C.byref(nm)))
+        return nm.value, match[: len(k1)]
+
+    def match_triangulation(self, keys_un1, desc1, free1, fv1, keys_un2, desc2, free2, fv2, F12, epipole, scale_factors,
+                            level_sigma2, mark_matched=False, check_ori=True):
+        """ORBmatcher::SearchForTriangulation (include/ORBmatcher.h:133-144), monocular.  Returns
+        (nmatches, matches12[n1])."""
+        k1 = np.ascontiguousarray(keys_un1, KP_DTYPE)
+        k2 = np.ascontiguousarray(keys_un2, KP_DTYPE)
+        d1, d2 = np.ascontiguousarray(desc1, np.uint8), np.ascontiguousarray(desc2, np.uint8)
+        f1, f2 = np.ascontiguousarray(free1, np.uint8), np.ascontiguousarray(free2, np.uint8)
+        a = [np.ascontiguousarray(x, np.int32) for x in fv1]
+        b = [np.ascontiguousarray(x, np.int32) for x in fv2]
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        ep = None if epipole is None else np.ascontiguousarray(epipole, np.float32)
+        sc = np.ascontiguousarray(scale_factors, np.float32)
+        sg = np.ascontiguousarray(level_sigma2, np.float32)
+        match = np.full(max(len(k1), 1), -1, np.int32)
+        nm = C.c_int(0)
+        _check(lib().orb_match_triangulation(self.h, _p(k1), _p(d1), _p(f1), len(k1), _p(a[0]), _p(a[1]), _p(a[2]),
+                                             len(a[0]), _p(k2), _p(d2), _p(f2), len(k2), _p(b[0]), _p(b[1]), _p(b[2]),
+                                             len(b[0]), _p(F), _p(ep), _p(sc), _p(sg), len(sc), int(mark_matched),
+                                             int(check_ori), _p(match), C.byref(nm)))
         return nm.value, match[: len(k1)]
 
 

@@ -42,7 +42,7 @@ public:
 
     // Declared by the reference, defined nowhere in it: kept for source compatibility.  Their candidate
     // loops exist in liborbhip as array-level entry points (orb_match_local_map, orb_match_projected,
-    // orb_match_best, orb_match_bow_keyframes in orb_hip.h); the pose algebra and the map surgery around
+    // orb_match_best, orb_match_bow_keyframes, orb_match_triangulation in orb_hip.h); the pose algebra and the map surgery around
     // them need KeyFrame / MapPoint / Sim3 objects that live in the reference's source tree.
     int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3);
     int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound,

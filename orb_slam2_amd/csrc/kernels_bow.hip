@@ -524,22 +524,40 @@ void orb_bow_state_free(void* p) {
 int orb_ctx_device(const orb_ctx* c);
 void** orb_ctx_bow_state(orb_ctx* c);
 
+// The context's bag-of-words scratch (device block, page-locked block, stream), created on first use.
+static int bow_state(orb_ctx* c, BowState** out) {
+    void** slot = orb_ctx_bow_state(c);
+    if (!*slot) {
+        BowState* ns = new (std::nothrow) BowState();
+        if (!ns) return ORB_ERR_NOMEM;
+        hipError_t e = hipStreamCreateWithFlags(&ns->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ns;
+            orb_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            return ORB_ERR_HIP;
+        }
+        *slot = ns;
+    }
+    *out = (BowState*)*slot;
+    return ORB_OK;
+}
+
 static int check_feature_vector(const char* who, const int* node, const int* offsets, const int* index, int nfv, int n,
                                 std::vector<uint8_t>& seen) {
     if (nfv < 0 || (nfv > 0 && (!node || !offsets || !index)) || (offsets && nfv > 0 && offsets[0] != 0)) {
-        orb_set_error("orb_match_bow: bad %s feature vector", who);
+        orb_set_error("bag-of-words matcher: bad %s feature vector", who);
         return ORB_ERR_INVALID;
     }
     seen.assign((size_t)(n > 0 ? n : 1), 0);
     for (int a = 0; a < nfv; a++) {
         if ((a > 0 && node[a] <= node[a - 1]) || offsets[a + 1] < offsets[a]) {
-            orb_set_error("orb_match_bow: %s feature vector: node ids and offsets must ascend", who);
+            orb_set_error("bag-of-words matcher: %s feature vector: node ids and offsets must ascend", who);
             return ORB_ERR_INVALID;
         }
         for (int o = offsets[a]; o < offsets[a + 1]; o++) {
             const int i = index[o];
             if (i < 0 || i >= n || seen[(size_t)i]) {  // a feature belongs to one node (FeatureVector::addFeature is called once per feature)
-                orb_set_error("orb_match_bow: %s feature vector names feature %d twice or out of range", who, i);
+                orb_set_error("bag-of-words matcher: %s feature vector names feature %d twice or out of range", who, i);
                 return ORB_ERR_INVALID;
             }
             seen[(size_t)i] = 1;
@@ -587,19 +605,8 @@ static int match_bow(orb_ctx* c, const orb_keypoint* kf_keys_un, const uint8_t* 
     }
     if (segs.empty() || nf == 0 || nkf == 0) return ORB_OK;
     HIP_TRY(hipSetDevice(orb_ctx_device(c)));
-    void** slot = orb_ctx_bow_state(c);
-    if (!*slot) {
-        BowState* ns = new (std::nothrow) BowState();
-        if (!ns) return ORB_ERR_NOMEM;
-        hipError_t e = hipStreamCreateWithFlags(&ns->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) {
-            delete ns;
-            orb_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
-            return ORB_ERR_HIP;
-        }
-        *slot = ns;
-    }
-    BowState* st = (BowState*)*slot;
+    BowState* st = nullptr;
+    if ((rc = bow_state(c, &st))) return rc;
     const int nKfIdx = kf_fv_offsets[kf_nfv], nFIdx = f_fv_offsets[f_nfv], nsegs = (int)segs.size();
     // one block in: segments, index lists, descriptors, validity, angles; one block out: matches, count
     size_t o = 0;
@@ -646,6 +653,183 @@ static int match_bow(orb_ctx* c, const orb_keypoint* kf_keys_un, const uint8_t* 
     HIP_TRY(hipMemcpyAsync(h + oMatch, d + oMatch, oBin - oMatch, hipMemcpyDeviceToHost, st->stream));
     HIP_TRY(hipStreamSynchronize(st->stream));
     memcpy(match_kf, h + oMatch, (size_t)nf * 4);
+    *nmatches = *(const int*)(h + oCount);
+    return ORB_OK;
+}
+
+// ---- SearchForTriangulation ------------------------------------------------------------------------
+// ORBmatcher::SearchForTriangulation (include/ORBmatcher.h:133-144) with CheckDistEpipolarLine (:196), declared
+// by the reference and defined nowhere in it; the loops are upstream ORB-SLAM2's, monocular members only.
+// Same node-by-node walk as k_bow_match.  A candidate of the second keyframe must be free (no map point),
+// at most TH_LOW away, farther from the epipole than 10 * sqrt(scale of its level) pixels and within the
+// chi-square bound of the epipolar line of the first keypoint; among those the smallest distance wins, the
+// LAST one among equals ('dist > bestDist' skips, an equal distance replaces).
+struct TriParams {
+    float F[9];      // F12, row-major
+    float ex, ey;    // epipole of keyframe 1 in keyframe 2
+    int useEpipole, nlevels, markMatched;
+};
+
+__global__ __launch_bounds__(256) void k_tri_match(const BowSegment* __restrict__ segs, int nsegs,
+                                                   const int* __restrict__ idx1, const uint8_t* __restrict__ desc1,
+                                                   const uint8_t* __restrict__ free1, const float4* __restrict__ kp1,
+                                                   const int* __restrict__ idx2, const uint8_t* __restrict__ desc2,
+                                                   const uint8_t* __restrict__ free2, const float4* __restrict__ kp2,
+                                                   const float* __restrict__ scale, const float* __restrict__ sigma2,
+                                                   TriParams P, int* __restrict__ match12, int* __restrict__ binOf) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + wave;
+    if (s >= nsegs) return;
+    const BowSegment sg = segs[s];
+    unsigned long long taken0 = 0ull, taken1 = 0ull;  // as in k_bow_match; only set when P.markMatched
+    for (int i1 = 0; i1 < sg.kfCount; i1++) {
+        const int r1 = idx1[sg.kfStart + i1];
+        if (!free1[r1]) continue;  // "if there is already a MapPoint skip"
+        const float4 k1 = kp1[r1];  // x, y, angle, octave
+        // epipolar line in the second image, l = x1' F12 = [a b c]
+        const float a = __fadd_rn(__fadd_rn(__fmul_rn(k1.x, P.F[0]), __fmul_rn(k1.y, P.F[3])), P.F[6]);
+        const float b = __fadd_rn(__fadd_rn(__fmul_rn(k1.x, P.F[1]), __fmul_rn(k1.y, P.F[4])), P.F[7]);
+        const float c = __fadd_rn(__fadd_rn(__fmul_rn(k1.x, P.F[2]), __fmul_rn(k1.y, P.F[5])), P.F[8]);
+        const float den = __fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b));
+        const uint4 a0 = ((const uint4*)(desc1 + (size_t)r1 * 32))[0], a1 = ((const uint4*)(desc1 + (size_t)r1 * 32))[1];
+        uint32_t best = 0xffffffffu;
+        for (int p = lane, t = 0; p < sg.fCount; p += 64, t++) {
+            const bool taken = t < 64 ? ((taken0 >> t) & 1ull) : ((taken1 >> (t - 64)) & 1ull);
+            if (taken) continue;
+            const int r2 = idx2[sg.fStart + p];
+            if (!free2[r2]) continue;
+            const int dist = hamming_rows(a0, a1, desc2 + (size_t)r2 * 32);
+            if (dist > M_TH_LOW) continue;
+            const float4 k2 = kp2[r2];
+            const int oct = (int)k2.w;
+            if (oct < 0 || oct >= P.nlevels) continue;  // no scale factor / sigma for that level
+            if (P.useEpipole) {
+                const float dx = __fsub_rn(P.ex, k2.x), dy = __fsub_rn(P.ey, k2.y);
+                if (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < __fmul_rn(100.f, scale[oct])) continue;
+            }
+            const float num = __fadd_rn(__fadd_rn(__fmul_rn(a, k2.x), __fmul_rn(b, k2.y)), c);
+            if (den == 0.f) continue;
+            const float dsqr = __fdiv_rn(__fmul_rn(num, num), den);
+            if (!((double)dsqr < 3.84 * (double)sigma2[oct])) continue;
+            best = min(best, ((uint32_t)dist << 16) | (uint32_t)(0xffff - p));
+        }
+        best = wave_min_u32(best);
+        if (best != 0xffffffffu) {
+            const int p = 0xffff - (int)(best & 0xffffu);
+            if (lane == (p & 63)) {
+                const int t = p >> 6;
+                if (P.markMatched) {
+                    if (t < 64) taken0 |= 1ull << t; else taken1 |= 1ull << (t - 64);
+                }
+                const int r2 = idx2[sg.fStart + p];
+                match12[r1] = r2;
+                binOf[r1] = rot_bin(k1.z, kp2[r2].z);
+            }
+        }
+    }
+}
+
+extern "C" int orb_match_triangulation(orb_ctx* c, const orb_keypoint* keys_un1, const uint8_t* desc1,
+                                       const uint8_t* free1, int n1, const int* fv_node1, const int* fv_offsets1,
+                                       const int* fv_index1, int nfv1, const orb_keypoint* keys_un2, const uint8_t* desc2,
+                                       const uint8_t* free2, int n2, const int* fv_node2, const int* fv_offsets2,
+                                       const int* fv_index2, int nfv2, const float F12[9], const float epipole[2],
+                                       const float* scale_factors, const float* level_sigma2, int nlevels,
+                                       int mark_matched, int check_ori, int* matches12, int* nmatches) {
+    if (!c || !nmatches || n1 < 0 || n2 < 0 || !F12 || !scale_factors || !level_sigma2 || nlevels < 1 || nlevels > 255 ||
+        (n1 > 0 && (!matches12 || !desc1 || !keys_un1 || !free1)) || (n2 > 0 && (!desc2 || !keys_un2 || !free2))) {
+        orb_set_error("orb_match_triangulation: bad arguments");
+        return ORB_ERR_INVALID;
+    }
+    if (n1 > BOW_MAX_FEATURES || n2 > BOW_MAX_FEATURES) {
+        orb_set_error("orb_match_triangulation: %d / %d features, at most %d per side", n1, n2, BOW_MAX_FEATURES);
+        return ORB_ERR_UNSUPPORTED;
+    }
+    int rc;
+    std::vector<uint8_t> seen;
+    if ((rc = check_feature_vector("first", fv_node1, fv_offsets1, fv_index1, nfv1, n1, seen))) return rc;
+    if ((rc = check_feature_vector("second", fv_node2, fv_offsets2, fv_index2, nfv2, n2, seen))) return rc;
+    *nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    std::vector<BowSegment> segs;
+    for (int a = 0, b = 0; a < nfv1 && b < nfv2;) {
+        if (fv_node1[a] == fv_node2[b]) {
+            BowSegment sg = {fv_offsets1[a], fv_offsets1[a + 1] - fv_offsets1[a], fv_offsets2[b],
+                             fv_offsets2[b + 1] - fv_offsets2[b]};
+            if (sg.kfCount > 0 && sg.fCount > 0) segs.push_back(sg);
+            a++;
+            b++;
+        } else if (fv_node1[a] < fv_node2[b]) {
+            a++;
+        } else {
+            b++;
+        }
+    }
+    if (segs.empty() || n1 == 0 || n2 == 0) return ORB_OK;
+    HIP_TRY(hipSetDevice(orb_ctx_device(c)));
+    BowState* st = nullptr;
+    if ((rc = bow_state(c, &st))) return rc;
+    const int nIdx1 = fv_offsets1[nfv1], nIdx2 = fv_offsets2[nfv2], nsegs = (int)segs.size();
+    size_t o = 0;
+    const size_t oSeg = o;    o += align256((size_t)nsegs * sizeof(BowSegment));
+    const size_t oIdx1 = o;   o += align256((size_t)nIdx1 * 4);
+    const size_t oIdx2 = o;   o += align256((size_t)nIdx2 * 4);
+    const size_t oDesc1 = o;  o += align256((size_t)n1 * 32);
+    const size_t oDesc2 = o;  o += align256((size_t)n2 * 32);
+    const size_t oFree1 = o;  o += align256((size_t)n1);
+    const size_t oFree2 = o;  o += align256((size_t)n2);
+    const size_t oKp1 = o;    o += align256((size_t)n1 * 16);
+    const size_t oKp2 = o;    o += align256((size_t)n2 * 16);
+    const size_t oScale = o;  o += align256(256 * 4);
+    const size_t oSigma = o;  o += align256(256 * 4);
+    const size_t inBytes = o;
+    const size_t oMatch = o;  o += align256((size_t)n1 * 4);
+    const size_t oCount = o;  o += 256;
+    const size_t oBin = o;    o += align256((size_t)n1 * 4);
+    if ((rc = grow_dev(&st->dev, &st->devBytes, o))) return rc;
+    if ((rc = grow_pinned(&st->host, &st->hostBytes, o))) return rc;
+    uint8_t* h = (uint8_t*)st->host;
+    uint8_t* d = (uint8_t*)st->dev;
+    memcpy(h + oSeg, segs.data(), (size_t)nsegs * sizeof(BowSegment));
+    memcpy(h + oIdx1, fv_index1, (size_t)nIdx1 * 4);
+    memcpy(h + oIdx2, fv_index2, (size_t)nIdx2 * 4);
+    memcpy(h + oDesc1, desc1, (size_t)n1 * 32);
+    memcpy(h + oDesc2, desc2, (size_t)n2 * 32);
+    memcpy(h + oFree1, free1, (size_t)n1);
+    memcpy(h + oFree2, free2, (size_t)n2);
+    for (int i = 0; i < n1; i++) {
+        float* k = (float*)(h + oKp1) + 4 * (size_t)i;
+        k[0] = keys_un1[i].x, k[1] = keys_un1[i].y, k[2] = keys_un1[i].angle, k[3] = (float)keys_un1[i].octave;
+    }
+    for (int j = 0; j < n2; j++) {
+        float* k = (float*)(h + oKp2) + 4 * (size_t)j;
+        k[0] = keys_un2[j].x, k[1] = keys_un2[j].y, k[2] = keys_un2[j].angle, k[3] = (float)keys_un2[j].octave;
+    }
+    memcpy(h + oScale, scale_factors, (size_t)nlevels * 4);
+    memcpy(h + oSigma, level_sigma2, (size_t)nlevels * 4);
+    TriParams P;
+    memcpy(P.F, F12, sizeof(P.F));
+    P.ex = epipole ? epipole[0] : 0.f;
+    P.ey = epipole ? epipole[1] : 0.f;
+    P.useEpipole = epipole ? 1 : 0;
+    P.nlevels = nlevels;
+    P.markMatched = mark_matched ? 1 : 0;
+    HIP_TRY(hipMemcpyAsync(d, h, inBytes, hipMemcpyHostToDevice, st->stream));
+    HIP_TRY(hipMemsetAsync(d + oMatch, 0xff, (size_t)n1 * 4, st->stream));
+    hipLaunchKernelGGL(k_tri_match, dim3((nsegs + 3) / 4), dim3(256), 0, st->stream, (const BowSegment*)(d + oSeg), nsegs,
+                       (const int*)(d + oIdx1), d + oDesc1, d + oFree1, (const float4*)(d + oKp1), (const int*)(d + oIdx2),
+                       d + oDesc2, d + oFree2, (const float4*)(d + oKp2), (const float*)(d + oScale),
+                       (const float*)(d + oSigma), P, (int*)(d + oMatch), (int*)(d + oBin));
+    hipLaunchKernelGGL(k_bow_finish, dim3(1), dim3(256), 0, st->stream, n1, check_ori ? 1 : 0, (int*)(d + oMatch),
+                       (const int*)(d + oBin), (int*)(d + oCount));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        orb_set_error("triangulation match launch failed: %s", hipGetErrorString(e));
+        return ORB_ERR_HIP;
+    }
+    HIP_TRY(hipMemcpyAsync(h + oMatch, d + oMatch, oBin - oMatch, hipMemcpyDeviceToHost, st->stream));
+    HIP_TRY(hipStreamSynchronize(st->stream));
+    memcpy(matches12, h + oMatch, (size_t)n1 * 4);
     *nmatches = *(const int*)(h + oCount);
     return ORB_OK;
 }

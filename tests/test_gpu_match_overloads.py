@@ -1,6 +1,7 @@
 """GPU parity of the matcher overloads the reference declares without a body (include/ORBmatcher.h:39,
-110,146-184): the local-map projection search, the candidate loop of Fuse / SearchBySim3 and the
-keyframe-to-keyframe SearchByBoW, through the C ABI against the CPU oracle.  Indices bit-exact."""
+110,133-184): the local-map projection search, the candidate loop of Fuse / SearchBySim3, the
+keyframe-to-keyframe SearchByBoW and SearchForTriangulation, through the C ABI against the CPU oracle.
+Indices bit-exact."""
 import numpy as np
 import pytest
 
@@ -133,5 +134,56 @@ def test_search_by_bow_keyframes(hip, oracle, check_ori):
     n_kf, m_kf = c.match_bow(kp, a, ones, fv, kp, b, fv, 0.9, False)
     assert n_kk == n_ref and list(m_kk) == list(m_ref) == [-1, 1]
     assert n_kf == 2 and list(m_kf) == [0, 1]
+    c.close()
+    g.close()
+
+
+@pytest.mark.parametrize("mark_matched", [False, True])
+def test_search_for_triangulation(hip, oracle, mark_matched):
+    """Two views that differ by an image-plane translation t: F12 = [[0,0,-ty],[0,0,tx],[ty,-tx,0]], every
+    epipolar line runs along t through the first keypoint."""
+    w, h = 752, 480
+    e = oracle.Extractor(2000, 1.2, 8, 20, 7, oracle.QUIRKS_FORK)
+    k1, d1 = e.extract(synth_scene(w, h, frame_seed(3, 2)))
+    k2, d2 = e.extract(synth_scene(w, h, frame_seed(3, 2), shift=(2, 3), noise_seed=5))
+    arrays = synth_vocabulary(10, 4, seed=41, prune=0.05, stop=0.02)
+    g = hip.Vocabulary.from_arrays(10, 4, 0, 0, *arrays)
+    tabs = e.tables()
+    rng = np.random.default_rng(16)
+    f1 = (rng.random(len(k1)) < 0.7).astype(np.uint8)
+    f2 = (rng.random(len(k2)) < 0.7).astype(np.uint8)
+    c = hip.Context(2000, 1.2, 8, 20, 7, w, h, 1, 0, 0x1F)
+    dense = (float(np.median(k2["x"])), float(np.median(k2["y"])))
+    total = 0
+    for levelsup in (4, 2):
+        _, fv1 = g.transform(d1, levelsup)
+        _, fv2 = g.transform(d2, levelsup)
+        for (tx, ty), ep, ori in (((2, 3), None, True), ((3, 2), dense, True), ((-2, -3), (300.0, 200.0), False),
+                                  ((0, 0), None, True)):
+            F = np.array([[0, 0, -ty], [0, 0, tx], [ty, -tx, 0]], np.float32)
+            n_ref, m_ref = oracle.search_for_triangulation(k1, d1, f1, fv1, k2, d2, f2, fv2, F, ep, tabs["scale"],
+                                                           tabs["sigma2"], mark_matched, ori)
+            n_got, m_got = c.match_triangulation(k1, d1, f1, fv1, k2, d2, f2, fv2, F, ep, tabs["scale"], tabs["sigma2"],
+                                                 mark_matched, ori)
+            assert n_got == n_ref
+            np.testing.assert_array_equal(m_got, m_ref)
+            if (tx, ty) == (0, 0):
+                assert n_ref == 0  # a zero matrix gives den == 0: no candidate passes
+            total += n_ref
+            hit = m_ref[m_ref >= 0]
+            assert (f2[hit] == 1).all() and (f1[np.nonzero(m_ref >= 0)[0]] == 1).all()
+            if mark_matched:
+                assert len(np.unique(hit)) == len(hit)
+    assert total > 1500
+    # fewer levels in the tables than octaves in the frames: those candidates are left out, as in the oracle
+    F = np.array([[0, 0, -3], [0, 0, 2], [3, -2, 0]], np.float32)
+    n_ref, m_ref = oracle.search_for_triangulation(k1, d1, f1, fv1, k2, d2, f2, fv2, F, None, tabs["scale"][:3],
+                                                   tabs["sigma2"][:3], mark_matched, True)
+    n_got, m_got = c.match_triangulation(k1, d1, f1, fv1, k2, d2, f2, fv2, F, None, tabs["scale"][:3], tabs["sigma2"][:3],
+                                         mark_matched, True)
+    assert n_got == n_ref and (m_got == m_ref).all()
+    n, m = c.match_triangulation(k1[:0], d1[:0], f1[:0], ([], [0], []), k2, d2, f2, fv2, F, None, tabs["scale"],
+                                 tabs["sigma2"], mark_matched, True)
+    assert n == 0 and len(m) == 0
     c.close()
     g.close()

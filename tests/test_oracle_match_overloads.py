@@ -1,5 +1,5 @@
 """Known-answer tests of the oracle's restatements of the matcher overloads the reference only declares
-(include/ORBmatcher.h:39,110,146-184).  The reference holds no body and no test vector for them, so the
+(include/ORBmatcher.h:39,110,133-184).  The reference holds no body and no test vector for them, so the
 expected values are worked out by hand from the rules of upstream ORB-SLAM2 that the fork's header
 comments summarise: parity with the reference is unpinned for these functions."""
 import numpy as np
@@ -104,4 +104,50 @@ def test_bow_keyframes_strict_threshold_and_masks(oracle):
     a2 = np.zeros((2, 32), np.uint8)
     b2 = np.stack([_desc_with_bits(3), np.full(32, 0xFF, np.uint8)])
     n, m = oracle.search_by_bow_keyframes(kp, a2, ones, fv, kp, b2, ones, fv, 0.9, False)
+    assert n == 1 and list(m) == [0, -1]
+
+
+def test_triangulation_epipolar_gate_and_last_among_equals(oracle):
+    """View 2 = view 1 moved by (4, 0): epipolar lines are horizontal through the first keypoint."""
+    F = np.array([[0, 0, 0], [0, 0, 4], [0, -4, 0]], np.float32)
+    scale = (1.2 ** np.arange(8)).astype(np.float32)
+    sigma2 = (scale * scale).astype(np.float32)
+    k1 = _kps(oracle, [(100, 100, 0)])
+    d1 = np.zeros((1, 32), np.uint8)
+    fv1 = ([3], [0, 1], [0])
+    ones = lambda n: np.ones(n, np.uint8)
+    # candidates: on the line / 1 px off (1 < 3.84) / 3 px off (9 > 3.84) / 3 px off on level 4 (9 < 3.84 * 4.3)
+    k2 = _kps(oracle, [(104, 100, 0), (104, 101, 0), (104, 103, 0), (104, 103, 4)])
+    d2 = np.stack([_desc_with_bits(20), _desc_with_bits(10), _desc_with_bits(5), _desc_with_bits(8)])
+    fv2 = ([3], [0, 4], [0, 1, 2, 3])
+    n, m = oracle.search_for_triangulation(k1, d1, ones(1), fv1, k2, d2, ones(4), fv2, F, None, scale, sigma2, False, False)
+    assert n == 1 and list(m) == [3]  # distance 8 on level 4 beats 10; the distance-5 one fails the line test
+    n, m = oracle.search_for_triangulation(k1, d1, ones(1), fv1, k2[:3], d2[:3], ones(3), ([3], [0, 3], [0, 1, 2]), F, None,
+                                           scale, sigma2, False, False)
+    assert list(m) == [1]
+    # equal distances: the later candidate replaces the earlier one
+    d2e = np.stack([_desc_with_bits(10), _desc_with_bits(10)])
+    n, m = oracle.search_for_triangulation(k1, d1, ones(1), fv1, k2[:2], d2e, ones(2), ([3], [0, 2], [0, 1]), F, None, scale,
+                                           sigma2, False, False)
+    assert list(m) == [1]
+    # a candidate closer to the epipole than 10 px (level 0) is skipped: (104,101) is 9.5 px away, (104,100) 10.5 px
+    n, m = oracle.search_for_triangulation(k1, d1, ones(1), fv1, k2[:2], d2e, ones(2), ([3], [0, 2], [0, 1]), F,
+                                           (104.0, 110.5), scale, sigma2, False, False)
+    assert list(m) == [0]
+    # features that already hold a map point take no part, on either side
+    n, m = oracle.search_for_triangulation(k1, d1, ones(1), fv1, k2[:2], d2e, [1, 0], ([3], [0, 2], [0, 1]), F, None, scale,
+                                           sigma2, False, False)
+    assert list(m) == [0]
+    n, m = oracle.search_for_triangulation(k1, d1, [0], fv1, k2[:2], d2e, ones(2), ([3], [0, 2], [0, 1]), F, None, scale,
+                                           sigma2, False, False)
+    assert n == 0 and list(m) == [-1]
+    # two first-side features, one counterpart: upstream gives it to both, with marking on to the first only
+    k1b = _kps(oracle, [(100, 100, 0), (100, 100, 0)])
+    d1b = np.zeros((2, 32), np.uint8)
+    fv1b = ([3], [0, 2], [0, 1])
+    n, m = oracle.search_for_triangulation(k1b, d1b, ones(2), fv1b, k2[:1], d2e[:1], ones(1), ([3], [0, 1], [0]), F, None,
+                                           scale, sigma2, False, False)
+    assert n == 2 and list(m) == [0, 0]
+    n, m = oracle.search_for_triangulation(k1b, d1b, ones(2), fv1b, k2[:1], d2e[:1], ones(1), ([3], [0, 1], [0]), F, None,
+                                           scale, sigma2, True, False)
     assert n == 1 and list(m) == [0, -1]
