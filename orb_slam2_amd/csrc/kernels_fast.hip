@@ -45,6 +45,11 @@ static __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Number of lanes below this one whose bit is set in a wavefront mask (two instructions).
+static __device__ __forceinline__ int lane_rank(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
 // Three-input minimum / maximum as single instructions.  Written as min(a, min(b, c)) the compiler shares
 // the inner two-input results between neighbouring arcs and ends up with twice as many instructions.
 static __device__ __forceinline__ int imin3(int a, int b, int c) {
@@ -214,7 +219,6 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
     const int ly = two ? (lane >> 5) : 0, lx = two ? (lane & 31) : lane;
     const int rowsPerStep = two ? 2 : 1;
     const int steps = (ch + rowsPerStep - 1) / rowsPerStep;
-    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint16_t* cand = s_cand[wave];
     uint16_t* corn = s_corn[wave];
     const int cellCap = g->cellCap;
@@ -239,30 +243,32 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
             }
             const unsigned long long m = __ballot(corner);
             if (corner) {
-                const int pos = nCorn + __popcll(m & below);
+                const int pos = nCorn + lane_rank(m);
                 if (pos < CORN_CAP) corn[pos] = (uint16_t)q;
             }
             nCorn += __popcll(m);
             head += count;
         };
         {
+            // An adjacent compass pair darker than v - th:  max(min(S,N), min(E,W)) < v - th; one brighter than
+            // v + th:  min(max(S,N), max(E,W)) > v + th; either one:  max(v - m1, m2 - v) > th.  Lanes outside the
+            // cell (they read tile bytes that belong to no pixel of it) compare against a threshold no difference
+            // of two bytes reaches, so that the test is one compare whose result is the wavefront mask.
             const uint8_t* c = &tile[(ly + 3) * TILE_PITCH + lx + 3];
-            int y = ly;
-            for (int p = 0; p < steps; p++, y += rowsPerStep, c += rowsPerStep * TILE_PITCH) {
-                // (lanes outside the cell read tile bytes that belong to no pixel of it; their result is masked)
+            auto prefilter = [&](unsigned q, int thLane) {  // q = lx | y << 8, the queue entry of this lane's pixel
                 const int v = c[0];
                 const int pS = c[3 * TILE_PITCH], pE = c[3], pN = c[-3 * TILE_PITCH], pW = c[-3];
-                // an adjacent compass pair darker than v - th, or one brighter than v + th: eight compares whose
-                // results are combined as lane masks on the scalar unit
-                const int lo = v - th, hi = v + th;
-                const bool darker = ((pS < lo) | (pN < lo)) & ((pE < lo) | (pW < lo));
-                const bool brighter = ((pS > hi) | (pN > hi)) & ((pE > hi) | (pW > hi));
-                const bool pass = xin & (y < ch) & (darker | brighter);
+                const int m1 = max(min(pS, pN), min(pE, pW)), m2 = min(max(pS, pN), max(pE, pW));
+                const bool pass = max(v - m1, m2 - v) > thLane;
                 const unsigned long long m = __ballot(pass);
-                if (pass) cand[(tail + __popcll(m & below)) & 127] = (uint16_t)(lx | (y << 8));
+                if (pass) cand[(tail + lane_rank(m)) & 127] = (uint16_t)q;
                 tail += __popcll(m);
                 if (tail - head >= 64) score_chunk(64);
-            }
+            };
+            const int thIn = xin ? th : 0x7fff;
+            unsigned q = (unsigned)lx | ((unsigned)ly << 8);
+            for (int p = 0; p + 1 < steps; p++, q += (unsigned)rowsPerStep << 8, c += rowsPerStep * TILE_PITCH) prefilter(q, thIn);
+            prefilter(q, ly + (steps - 1) * rowsPerStep < ch ? thIn : 0x7fff);  // only the last step can reach below the cell
         }
         if (tail > head) score_chunk(tail - head);
         wave_lds_sync();
@@ -305,7 +311,7 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
                     px = q & 255;
                     py = q >> 8;
                 }
-                const int pos = run + __popcll(b & below);
+                const int pos = run + lane_rank(b);
                 const int sc = score[(py + 1) * SCORE_PITCH + px + 1];
                 if (pos < cellCap) out[pos] = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)sc << 16);
             }
