@@ -63,47 +63,78 @@ static __device__ __forceinline__ int imax3(int a, int b, int c) {
     return r;
 }
 
-// t* = max(A, B) - 1 with A = max over the 16 arcs of 9 contiguous ring pixels
-// of min(v - ring), B likewise for (ring - v)   (cv::cornerScore<16>).
+// a * b + c on 24-bit factors in one instruction (left to itself the compiler forms both signs of the
+// difference and selects).
+static __device__ __forceinline__ int imad24(int a, int b, int c) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// Maximum over the 16 arcs of 9 contiguous ring pixels of the arc's smallest entry: 16 -> 6 -> 2 -> 1.
+static __device__ __forceinline__ int arc_max_min(const int* e) {
+    int lo3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) lo3[k] = imin3(e[k], e[(k + 1) & 15], e[(k + 2) & 15]);
+    int a9[16];  // minimum over the arc of 9 starting at k
+#pragma unroll
+    for (int k = 0; k < 16; k++) a9[k] = imin3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
+    return max(imax3(imax3(a9[0], a9[1], a9[2]), imax3(a9[3], a9[4], a9[5]), imax3(a9[6], a9[7], a9[8])),
+               imax3(imax3(a9[9], a9[10], a9[11]), imax3(a9[12], a9[13], a9[14]), a9[15]));
+}
+
+// Minimum over the 16 arcs of the arc's largest entry.
+static __device__ __forceinline__ int arc_min_max(const int* e) {
+    int hi3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) hi3[k] = imax3(e[k], e[(k + 1) & 15], e[(k + 2) & 15]);
+    int b9[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) b9[k] = imax3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
+    return min(imin3(imin3(b9[0], b9[1], b9[2]), imin3(b9[3], b9[4], b9[5]), imin3(b9[6], b9[7], b9[8])),
+               imin3(imin3(b9[9], b9[10], b9[11]), imin3(b9[12], b9[13], b9[14]), b9[15]));
+}
+
+// t* = max(A, B) - 1 with A = max over the arcs of min(v - ring), B likewise for (ring - v)
+// (cv::cornerScore<16>), exact whenever t* >= th and below th otherwise.  A side can only reach th if its
+// adjacent compass pair clears th (every arc of 9 holds one), so the side with the larger compass value is
+// evaluated -- the differences are formed with that side's sign -- and the other one only for pixels whose
+// compass points clear th on both sides (one wavefront-wide branch).
 template <int TILE_PITCH>
-static __device__ __forceinline__ int fast_score(const uint8_t* c) {
+static __device__ __forceinline__ int fast_score(const uint8_t* c, int th) {
     // c points at the centre inside the LDS tile
     const int v = c[0];
-    int d[16];
-    d[0] = v - c[3 * TILE_PITCH + 0];
-    d[1] = v - c[3 * TILE_PITCH + 1];
-    d[2] = v - c[2 * TILE_PITCH + 2];
-    d[3] = v - c[1 * TILE_PITCH + 3];
-    d[4] = v - c[0 * TILE_PITCH + 3];
-    d[5] = v - c[-1 * TILE_PITCH + 3];
-    d[6] = v - c[-2 * TILE_PITCH + 2];
-    d[7] = v - c[-3 * TILE_PITCH + 1];
-    d[8] = v - c[-3 * TILE_PITCH + 0];
-    d[9] = v - c[-3 * TILE_PITCH - 1];
-    d[10] = v - c[-2 * TILE_PITCH - 2];
-    d[11] = v - c[-1 * TILE_PITCH - 3];
-    d[12] = v - c[0 * TILE_PITCH - 3];
-    d[13] = v - c[1 * TILE_PITCH - 3];
-    d[14] = v - c[2 * TILE_PITCH - 2];
-    d[15] = v - c[3 * TILE_PITCH - 1];
-    int lo3[16], hi3[16];
+    int r[16];
+    r[0] = c[3 * TILE_PITCH + 0];
+    r[1] = c[3 * TILE_PITCH + 1];
+    r[2] = c[2 * TILE_PITCH + 2];
+    r[3] = c[1 * TILE_PITCH + 3];
+    r[4] = c[0 * TILE_PITCH + 3];
+    r[5] = c[-1 * TILE_PITCH + 3];
+    r[6] = c[-2 * TILE_PITCH + 2];
+    r[7] = c[-3 * TILE_PITCH + 1];
+    r[8] = c[-3 * TILE_PITCH + 0];
+    r[9] = c[-3 * TILE_PITCH - 1];
+    r[10] = c[-2 * TILE_PITCH - 2];
+    r[11] = c[-1 * TILE_PITCH - 3];
+    r[12] = c[0 * TILE_PITCH - 3];
+    r[13] = c[1 * TILE_PITCH - 3];
+    r[14] = c[2 * TILE_PITCH - 2];
+    r[15] = c[3 * TILE_PITCH - 1];
+    const int m1 = max(min(r[0], r[8]), min(r[4], r[12])), m2 = min(max(r[0], r[8]), max(r[4], r[12]));
+    const int darkv = v - m1, brightv = m2 - v;  // the prefilter's two quantities
+    const bool bright = brightv > darkv;
+    const int sgn = bright ? 1 : -1, base = bright ? -v : v;
+    int e[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        lo3[k] = imin3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
-        hi3[k] = imax3(d[k], d[(k + 1) & 15], d[(k + 2) & 15]);
+    for (int k = 0; k < 16; k++) e[k] = imad24(r[k], sgn, base);  // ring - v, or v - ring
+    int A = arc_max_min(e);
+    const bool both = min(darkv, brightv) > th;
+    if (__ballot(both) != 0ull) {  // (diagonal edges do this: common enough to keep it short)
+        const int A2 = -arc_min_max(e);  // the other side's differences are -e
+        if (both) A = max(A, A2);
     }
-    int a9[16], b9[16];  // min / max over the arc of 9 starting at k
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        a9[k] = imin3(lo3[k], lo3[(k + 3) & 15], lo3[(k + 6) & 15]);
-        b9[k] = imax3(hi3[k], hi3[(k + 3) & 15], hi3[(k + 6) & 15]);
-    }
-    // A = max over arcs of min(d), Bn = min over arcs of max(d) = -B: 16 -> 6 -> 2 -> 1
-    const int A = max(imax3(imax3(a9[0], a9[1], a9[2]), imax3(a9[3], a9[4], a9[5]), imax3(a9[6], a9[7], a9[8])),
-                      imax3(imax3(a9[9], a9[10], a9[11]), imax3(a9[12], a9[13], a9[14]), a9[15]));
-    const int Bn = min(imin3(imin3(b9[0], b9[1], b9[2]), imin3(b9[3], b9[4], b9[5]), imin3(b9[6], b9[7], b9[8])),
-                       imin3(imin3(b9[9], b9[10], b9[11]), imin3(b9[12], b9[13], b9[14]), b9[15]));
-    return max(A, -Bn) - 1;
+    return A - 1;
 }
 
 // The kernel waits on LDS round trips far more than it computes: the register budget is set so that the
@@ -237,7 +268,7 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
             if (lane < count) {
                 q = cand[(head + lane) & 127];
                 const int qx = q & 255, qy = q >> 8;
-                const int t = fast_score<TILE_PITCH>(&tile[(qy + 3) * TILE_PITCH + qx + 3]);
+                const int t = fast_score<TILE_PITCH>(&tile[(qy + 3) * TILE_PITCH + qx + 3], th);
                 corner = t >= th;
                 if (corner) score[(qy + 1) * SCORE_PITCH + qx + 1] = (uint8_t)t;
             }
