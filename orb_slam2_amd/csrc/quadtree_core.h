@@ -48,7 +48,12 @@ static inline int qt_host_fetch_add(int* p, int v) {
 #define QT_DEPTH(n) ((n).depthFlags & 0xff)
 
 #define QT_MAX_BIN_BITS 12  // the key sort uses 2^bits buckets, bits chosen per launch (QtBins)
-#define QT_SMALL_BIN 40   // buckets up to this size are sorted by one thread
+#define QT_SMALL_BIN 40   // buckets up to this size are ordered by counting, larger ones by the bitonic network
+#ifdef ORB_HOST_EMU
+#define QT_RANK_K 64      // keys one thread holds per round of that counting (the emulation has one thread)
+#else
+#define QT_RANK_K 8
+#endif
 
 #define QT_BIG_LIST 128   // nodes handed to the whole workgroup by the winner selection
 #define QT_BIN_INTS(bits) ((2 << (bits)) + 1)  // ints of bucket scratch: 2^bits + 1 starts, 2^bits cursors
@@ -259,9 +264,24 @@ QT_FN void qt_children(const unsigned long long* s, const OrbNode& nd, int* b, i
         b[2] = q >= 3 ? nd.lo : nd.hi;
         return;
     }
-    b[0] = qt_lower_bound(s, nd.lo, nd.hi, (prefix | 1u) << shift);
-    b[1] = qt_lower_bound(s, b[0], nd.hi, (prefix | 2u) << shift);
-    b[2] = qt_lower_bound(s, b[1], nd.hi, (prefix | 3u) << shift);
+    // three lower bounds over the same range, advanced together: their loads are independent of each other,
+    // so the three searches take the time of one
+    const uint32_t k1 = (prefix | 1u) << shift, k2 = (prefix | 2u) << shift, k3 = (prefix | 3u) << shift;
+    int lo1 = nd.lo, hi1 = nd.hi, lo2 = nd.lo, hi2 = nd.hi, lo3 = nd.lo, hi3 = nd.hi;
+    while (lo1 < hi1 || lo2 < hi2 || lo3 < hi3) {
+        // (a finished search probes index lo == hi, which may be nd.hi: clamped into the range, result ignored)
+        const int m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1, m3 = (lo3 + hi3) >> 1;
+        const int last = nd.hi - 1;
+        const uint32_t c1 = (uint32_t)(s[m1 < last ? m1 : last] >> 32);
+        const uint32_t c2 = (uint32_t)(s[m2 < last ? m2 : last] >> 32);
+        const uint32_t c3 = (uint32_t)(s[m3 < last ? m3 : last] >> 32);
+        if (lo1 < hi1) { if (c1 < k1) lo1 = m1 + 1; else hi1 = m1; }
+        if (lo2 < hi2) { if (c2 < k2) lo2 = m2 + 1; else hi2 = m2; }
+        if (lo3 < hi3) { if (c3 < k3) lo3 = m3 + 1; else hi3 = m3; }
+    }
+    b[0] = lo1;
+    b[1] = lo2;
+    b[2] = lo3;
 }
 
 QT_FN int qt_child_flags(int q, int cnt, int n3quirk) {
@@ -528,7 +548,7 @@ QT_FN int qt_select(const unsigned long long* sorted, const OrbNode& nd) {
 // Entries are first bucketed by the leading bits of the quadtree path (one
 // histogram + one scatter over all keys, LDS counters), which already puts
 // every bucket into its final slice; buckets are then ordered internally, small
-// ones by one thread each, large ones by the whole workgroup.  Entries are
+// ones by counting (one key per thread), large ones by the whole workgroup.  Entries are
 // unique, so the result does not depend on the order atomics were served in.
 QT_FN void qt_sort_keys(const unsigned long long* tmp, unsigned long long* sorted, int n, int nIni, const QtBins bins,
                         QtShared* sh) {
@@ -536,7 +556,11 @@ QT_FN void qt_sort_keys(const unsigned long long* tmp, unsigned long long* sorte
     const uint32_t maxCode = ((uint32_t)nIni << (2 * ORB_CODE_DEPTH)) - 1u;  // nIni <= 16
     int bits = 0;
     while ((maxCode >> bits) != 0u && bits < 32) bits++;
-    const int shift = bits > bins.bits ? bits - bins.bits : 0;
+    // about four keys per bucket, as many buckets as the scratch holds at most: the passes over the bucket
+    // arrays are a fixed cost that a level with few keys should not pay in full
+    int useBits = bins.bits < 4 ? bins.bits : 4;
+    while ((4 << useBits) < n && useBits < bins.bits) useBits++;
+    const int shift = bits > useBits ? bits - useBits : 0;
     const int nb = (int)(maxCode >> shift) + 1;  // <= 2^bins.bits
     int* const binStart = bins.start;
     int* const binCursor = bins.cursor;
@@ -554,26 +578,51 @@ QT_FN void qt_sort_keys(const unsigned long long* tmp, unsigned long long* sorte
         sorted[pos] = e;
     }
     QT_BARRIER();
-    // binCursor is free again: it now collects the buckets that need the workgroup
-    for (int b = t; b < nb; b += T) {
-        const int lo = binStart[b], m = binStart[b + 1] - lo;
-        if (m <= 1) continue;
-        if (m > QT_SMALL_BIN) {
-            binCursor[QT_ATOMIC_ADD(&sh->nBig, 1)] = b;
-            continue;
+    // Order inside the buckets.  Buckets of up to QT_SMALL_BIN entries: every key counts the entries of its
+    // bucket that are smaller (entries are unique, so that count is its place), all keys at once, holds
+    // itself in a register across a barrier and moves.  The keys are taken in rounds of QT_RANK_K per
+    // thread; a round ends on a bucket boundary, so no key moves onto one that has not been read yet.
+    // binCursor is free again: it collects the larger buckets, which the whole workgroup sorts below.
+    for (int base = 0; base < n;) {
+        int end = base + QT_RANK_K * T;
+        if (end >= n) {
+            end = n;
+        } else {
+            const int b = (int)((uint32_t)(sorted[end] >> 32) >> shift);
+            end = binStart[b];
+            if (end <= base) end = binStart[b + 1];  // one bucket fills the round: a large one, nothing to do here
         }
-        unsigned long long* a = sorted + lo;
-        for (int i = 1; i < m; i++) {
-            const unsigned long long x = a[i];
-            int j = i - 1;
-            while (j >= 0 && a[j] > x) {
-                a[j + 1] = a[j];
-                j--;
+        unsigned long long held[QT_RANK_K];
+        int dst[QT_RANK_K];
+#ifndef ORB_HOST_EMU
+#pragma unroll
+#endif
+        for (int k = 0; k < QT_RANK_K; k++) {
+            const int r = base + t + k * T;
+            dst[k] = -1;
+            if (r < end) {
+                const unsigned long long e = sorted[r];
+                const int b = (int)((uint32_t)(e >> 32) >> shift);
+                const int lo = binStart[b], m = binStart[b + 1] - lo;
+                if (m > QT_SMALL_BIN) {
+                    if (r == lo) binCursor[QT_ATOMIC_ADD(&sh->nBig, 1)] = b;
+                } else if (m > 1) {
+                    int rank = 0;
+                    for (int j = 0; j < m; j++) rank += sorted[lo + j] < e;
+                    held[k] = e;
+                    dst[k] = lo + rank;
+                }
             }
-            a[j + 1] = x;
         }
+        QT_BARRIER();
+#ifndef ORB_HOST_EMU
+#pragma unroll
+#endif
+        for (int k = 0; k < QT_RANK_K; k++)
+            if (dst[k] >= 0) sorted[dst[k]] = held[k];
+        QT_BARRIER();
+        base = end;
     }
-    QT_BARRIER();
     const int nBig = sh->nBig;
     for (int k = 0; k < nBig; k++) {
         const int b = binCursor[k];
