@@ -18,6 +18,9 @@
 //    frame feature taken by an earlier one is skipped by the later ones, :188)
 //    and scans the frame's features of the node 64 at a time; the taken flags
 //    live in lane registers.  k_bow_finish applies the rotation histogram.
+//  * k_tri_match walks the common nodes the same way for SearchForTriangulation
+//    (include/ORBmatcher.h:133-144): per candidate the distance, the epipole test and
+//    the epipolar-line test.
 #include <hip/hip_runtime.h>
 
 #include <cmath>

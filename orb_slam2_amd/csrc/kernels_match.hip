@@ -20,9 +20,16 @@
 //     (vMatchedDistance / map-point occupancy): it filters the query's list by
 //     that state, reduces (distance, position) over the lanes and updates the
 //     state, all in LDS.  Queries with an empty list are skipped; three wavefronts
-//     stage the lists of the next 64 queries while one resolves the current 64.  The rotation histogram is filled afterwards from
-//     the recorded acceptances (the reference never removes a stolen match from
-//     rotHist, so every acceptance counts once).
+//     stage the lists of the next 64 queries while one resolves the current 64.
+//     The rotation histogram is filled afterwards from the recorded acceptances
+//     (the reference never removes a stolen match from rotHist, so every
+//     acceptance counts once).
+//
+// The same grid serves the overloads the reference only declares
+// (include/ORBmatcher.h:39,146-184): k_match_resolve<2> applies the local-map
+// rule (best and second best with their pyramid levels), and k_match_best takes
+// every query's best candidate on its own (Fuse, SearchBySim3), with no lists
+// and no sequential stage.
 #include <hip/hip_runtime.h>
 
 #include <climits>
