@@ -9,6 +9,7 @@
 //   (fx = fy = 500, principal point at the image centre, no distortion)
 //   environment ORBDEMO_VOC=<vocabulary text file> adds Frame::ComputeBoW on both frames, the L1 score of
 //   their bag-of-words vectors and ORBmatcher::SearchByBoW with frame A in the keyframe's place
+//   environment ORBDEMO_LOCALMAP=1 adds ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -83,6 +84,27 @@ int main(int argc, char** argv) {
         for (int i2 = 0; i2 < F2.N; i2++)
             for (int i = 0; i < F1.N && F2.mvpMapPoints[i2]; i++)
                 if (F2.mvpMapPoints[i2] == F1.mvpMapPoints[i]) { proj[i2] = i; break; }
+        // ORBDEMO_LOCALMAP=1: SearchByProjection(Frame&, vector<MapPoint*>&, th) on a cleared frame B.  Two of three
+        // points are in view, projected 3 / 2 pixels off their frame-A keypoint, at the keypoint's level, seen
+        // alternately head-on and from the side.
+        int nLocal = -1;
+        std::vector<int> local(F2.N, -1);
+        const bool doLocal = getenv("ORBDEMO_LOCALMAP") != nullptr;
+        if (doLocal) {
+            for (int i2 = 0; i2 < F2.N; i2++) F2.mvpMapPoints[i2] = static_cast<MapPoint*>(NULL);
+            for (int i = 0; i < F1.N; i++) {
+                MapPoint* mp = owned[i];
+                mp->mbTrackInView = (i % 3) != 0;
+                mp->mTrackProjX = F1.mvKeysUn[i].pt.x + 3.f;
+                mp->mTrackProjY = F1.mvKeysUn[i].pt.y + 2.f;
+                mp->mnTrackScaleLevel = F1.mvKeysUn[i].octave;
+                mp->mTrackViewCos = (i % 2) ? 0.999f : 0.9f;
+            }
+            nLocal = matcher.SearchByProjection(F2, owned, 3.f);
+            for (int i2 = 0; i2 < F2.N; i2++)
+                for (int i = 0; i < F1.N && F2.mvpMapPoints[i2]; i++)
+                    if (F2.mvpMapPoints[i2] == owned[i]) { local[i2] = i; break; }
+        }
         const std::vector<size_t> area = F2.GetFeaturesInArea(w / 2.f, h / 2.f, 60.f, 0, 2);
         const int dd = F1.N > 1 ? ORBmatcher::DescriptorDistance(F1.mDescriptors.row(0), F1.mDescriptors.row(1)) : -1;
 
@@ -138,6 +160,10 @@ int main(int argc, char** argv) {
                     put(fo, &it->second, 1);
                 }
             }
+        }
+        if (doLocal) {  // last section: match count and, per frame-B keypoint, the frame-A point it received
+            put(fo, &nLocal, 1);
+            put(fo, local.data(), local.size());
         }
         fclose(fo);
         for (MapPoint* p : owned) delete p;

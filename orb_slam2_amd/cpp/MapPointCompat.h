@@ -23,6 +23,14 @@ public:
     bool isBad() { return mbBad; }
     void SetBadFlag() { mbBad = true; }
 
+    // variables used by the tracking of the local map (include/MapPoint.h:87-93); Frame::isInFrustum fills them
+    float mTrackProjX = 0.f;
+    float mTrackProjY = 0.f;
+    float mTrackProjXR = 0.f;
+    int mnTrackScaleLevel = 0;
+    float mTrackViewCos = 0.f;
+    bool mbTrackInView = false;
+
 private:
     cv::Mat mWorldPos, mDescriptor;
     int mnObs;

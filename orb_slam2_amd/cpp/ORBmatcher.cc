@@ -133,6 +133,54 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
     return nmatches;
 }
 
+// include/ORBmatcher.h:197, declared only; upstream ORB-SLAM2: a smaller window when the point is seen
+// almost along its mean viewing direction.
+float ORBmatcher::RadiusByViewingCos(const float& viewCos) {
+    if (viewCos > 0.998) return 2.5;
+    return 4.0;
+}
+
+// include/ORBmatcher.h:24-39, declared only; upstream ORB-SLAM2's loop.  The points Frame::isInFrustum left in
+// view carry their projection, predicted level and viewing cosine; the search itself is orb_match_local_map.
+int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th) {
+    const bool bFactor = th != 1.0;
+    std::vector<float> u, v, radius;
+    std::vector<int> lmin, lmax, src;
+    std::vector<unsigned char> qdesc, qobs;
+    for (size_t iMP = 0; iMP < vpMapPoints.size(); iMP++) {
+        MapPoint* pMP = vpMapPoints[iMP];
+        if (!pMP->mbTrackInView) continue;
+        if (pMP->isBad()) continue;
+        const int nPredictedLevel = pMP->mnTrackScaleLevel;
+        float r = RadiusByViewingCos(pMP->mTrackViewCos);  // the window depends on the viewing direction
+        if (bFactor) r *= th;
+        u.push_back(pMP->mTrackProjX);
+        v.push_back(pMP->mTrackProjY);
+        radius.push_back(r * F.mvScaleFactors[nPredictedLevel]);
+        lmin.push_back(nPredictedLevel - 1);
+        lmax.push_back(nPredictedLevel);
+        cv::Mat dMP = pMP->GetDescriptor();
+        qdesc.insert(qdesc.end(), dMP.ptr<unsigned char>(), dMP.ptr<unsigned char>() + 32);
+        qobs.push_back(pMP->Observations() > 0 ? 1 : 0);
+        src.push_back((int)iMP);
+    }
+    const int nq = (int)u.size(), n2 = F.N;
+    if (nq == 0 || n2 == 0) return 0;
+    std::vector<unsigned char> occ(n2, 0), t2;
+    for (int i2 = 0; i2 < n2; i2++)
+        if (F.mvpMapPoints[i2] && F.mvpMapPoints[i2]->Observations() > 0) occ[i2] = 1;
+    std::vector<int> match2(n2, -1);
+    int nmatches = 0;
+    orb_ctx* ctx = F.mpORBextractorLeft->Context();
+    if (orb_match_local_map(ctx, u.data(), v.data(), radius.data(), lmin.data(), lmax.data(), qdesc.data(), qobs.data(),
+                            nq, (const orb_keypoint*)F.mvKeysUn.data(), packed(F.mDescriptors, t2), n2, F.mnImgWidth,
+                            F.mnImgHeight, occ.data(), match2.data(), TH_HIGH, mfNNratio, &nmatches))
+        fail("orb_match_local_map");
+    for (int i2 = 0; i2 < n2; i2++)
+        if (match2[i2] >= 0) F.mvpMapPoints[i2] = vpMapPoints[src[match2[i2]]];
+    return nmatches;
+}
+
 // FeatureVector -> CSR arrays (node ids ascend in map order)
 static void flatten(const DBoW2::FeatureVector& fv, std::vector<int>& node, std::vector<int>& off, std::vector<int>& idx) {
     node.clear();

@@ -40,11 +40,14 @@ public:
     int SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches);
     int SearchByBoW(const Frame& KF, Frame& F, std::vector<MapPoint*>& vpMapPointMatches);
 
+    // include/ORBmatcher.h:24-39 (tracking of the local map).  The reference declares it with its five steps and
+    // holds no body; the loop is upstream ORB-SLAM2's and runs on the GPU (orb_match_local_map).
+    int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3);
+
     // Declared by the reference, defined nowhere in it: kept for source compatibility.  Their candidate
     // loops exist in liborbhip as array-level entry points (orb_match_local_map, orb_match_projected,
     // orb_match_best, orb_match_bow_keyframes, orb_match_triangulation in orb_hip.h); the pose algebra and the map surgery around
     // them need KeyFrame / MapPoint / Sim3 objects that live in the reference's source tree.
-    int SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMapPoints, const float th = 3);
     int SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const std::set<MapPoint*>& sAlreadyFound,
                            const float th, const int ORBdist);
     int SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const std::vector<MapPoint*>& vpPoints,
@@ -67,6 +70,7 @@ protected:
     int SearchByBoWImpl(const std::vector<MapPoint*>& vpMapPointsKF, const std::vector<cv::KeyPoint>& vKeysUnKF,
                         const cv::Mat& descriptorsKF, const DBoW2::FeatureVector& vFeatVecKF, Frame& F,
                         std::vector<MapPoint*>& vpMapPointMatches);
+    float RadiusByViewingCos(const float& viewCos);  // include/ORBmatcher.h:197
     void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3);
 
     float mfNNratio;

@@ -73,7 +73,7 @@ def test_cpp_dropin_demo(oracle, tmp_path, preset):
         f.write(struct.pack("<iiiif", w, h, nf, window, ratio))
         f.write(a.tobytes())
         f.write(b.tobytes())
-    env = dict(os.environ, ORBHIP_QUIRKS=str(quirks))
+    env = dict(os.environ, ORBHIP_QUIRKS=str(quirks), ORBDEMO_LOCALMAP="1")
     subprocess.check_call([exe, fin, fout], env=env, timeout=120)
     raw = open(fout, "rb").read()
     cnt = np.frombuffer(raw, np.int32, 8)
@@ -119,6 +119,18 @@ def test_cpp_dropin_demo(oracle, tmp_path, preset):
     assert n_proj == npo
     assert (proj == np.where(match2 >= 0, match2, -1)).all()
     assert npo > 100
+    # SearchByProjection(Frame&, const vector<MapPoint*>&, th = 3) on the cleared frame B (last section of the file)
+    take(KP, n1); take(KP, n2); take(np.float32, 4)  # undistorted keypoints (equal to the raw ones here), bounds
+    n_local = int(take(np.int32, 1)[0])
+    local = take(np.int32, n2)
+    assert off == len(raw)
+    idx = np.nonzero(np.arange(n1) % 3 != 0)[0]
+    r = np.where(idx % 2 != 0, _f32(2.5), _f32(4.0)).astype(np.float32) * _f32(3.0)
+    lvl = ko1["octave"][idx].astype(np.int32)
+    nlo, m2 = oracle.search_local_map(ko1["x"][idx] + _f32(3.0), ko1["y"][idx] + _f32(2.0), r * scale[lvl], lvl - 1, lvl,
+                                      do1[idx], qobs[idx], ko2, do2, w, h, None, 100, ratio, quirks)
+    assert n_local == nlo and nlo > 100
+    assert (local == np.where(m2 >= 0, idx[np.maximum(m2, 0)], -1)).all()
 
 
 def test_cpp_dropin_demo_with_lens_distortion(oracle, tmp_path):
