@@ -222,6 +222,15 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     const bool fastLoad = wx0 >= 0 && wy0 >= 0 && py + 21 < L.h && xa + RAW_P <= L.w && (pitch & 3) == 0 &&
                           (((unsigned long long)img) & 3ull) == 0;
     const int off = fastLoad ? (wx0 - xa) : 0;
+    // the IC_Angle byte weights of this lane's five patch rows: requested now, used after the window is staged
+    const int icRow = lane_div<9>(lane), icGroup = lane - icRow * 9;
+    uint2 icm[5];
+    if (icRow < 7) {
+        const uint2* mk = (const uint2*)&g->icMask[off][icRow][icGroup][0];
+#pragma unroll
+        for (int it = 0; it < 5; it++)
+            if (icRow + 7 * it < 31) icm[it] = mk[it * 7 * 9];
+    }
     if (fastLoad) {
         // lane = (row within a group of five, dword); nine groups cover the 43 rows, all loads in flight at once.
         // The window's origin is the same for all lanes (scalar 64-bit address), a lane adds a 32-bit offset.
@@ -250,37 +259,25 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     }
     wave_lds_sync();
 
-    // Intensity centroid over the circular patch (rows v, half-width umax[|v|]).
-    const unsigned long long um = g->umaxPacked;
+    // Intensity centroid over the circular patch (rows v, half-width umax[|v|]): rows v = -15..15, aligned column
+    // groups 1..9 (they cover u = -15..15 for every `off`); lane = (row within a pass of seven, group), five passes
+    // cover the 31 rows.  Which bytes of a dword lie inside the patch row, and their weights u + 32 (positive for
+    // every dword a lane can hold; taken off again through the plain sum m00: sum u * I = sum (u + 32) * I -
+    // 32 * sum I), come from the table the host built for the context's umax (icm, fetched above).
     int m10 = 0, m01 = 0;
     {
-        // rows v = -15..15, aligned column groups 1..9 (they cover u = -15..15 for every `off`)
         const uint32_t* raw32 = (const uint32_t*)s_raw[wave];
-        // lane = (row within a pass of seven, dword group 1..9); five passes cover the 31 rows
-        const int rr = lane_div<9>(lane), q = 1 + (lane - rr * 9);
-        const int u0 = 4 * q - off - 21;  // u of the dword's first byte
-        // byte weights u + 32 = u0 + 32 + i (positive for every dword a lane can hold), taken off again through
-        // the plain sum m00: sum u * I = sum (u + 32) * I - 32 * sum I
-        uint32_t wU = (uint32_t)(u0 + 32);
-        wU |= wU << 8;
-        wU |= wU << 16;
-        wU += 0x03020100u;
         int m00 = 0;
-        if (rr < 7) {
+        if (icRow < 7) {
 #pragma unroll
             for (int it = 0; it < 5; it++) {
-                const int r = rr + 7 * it;
+                const int r = icRow + 7 * it;
                 if (r < 31) {
-                    const int v = r - 15, av = v < 0 ? -v : v;
-                    const int lim = (int)((um >> (4 * av)) & 15ull);
-                    const uint32_t w = raw32[(6 + r) * (RAW_P / 4) + q];
-                    // bytes lo..hi of the dword lie inside the patch row (|u| <= lim); none when lo > hi
-                    const int lo = max(0, -lim - u0), hi = min(3, lim - u0);
-                    const uint32_t in = lo <= hi ? (0xffffffffu << (8 * lo)) & (0xffffffffu >> (8 * (3 - hi))) : 0u;
-                    const int rowSum = (int)dot4_u8(w, in & 0x01010101u, 0u);
-                    m10 = (int)dot4_u8(w, in & wU, (uint32_t)m10);
+                    const uint32_t w = raw32[(6 + r) * (RAW_P / 4) + 1 + icGroup];
+                    const int rowSum = (int)dot4_u8(w, icm[it].x, 0u);
+                    m10 = (int)dot4_u8(w, icm[it].y, (uint32_t)m10);
                     m00 += rowSum;
-                    m01 += __mul24(v, rowSum);
+                    m01 += __mul24(r - 15, rowSum);
                 }
             }
         }

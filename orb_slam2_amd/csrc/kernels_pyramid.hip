@@ -137,7 +137,7 @@ template <bool AREA, int NT, bool PAIR>
 __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict__ src, int sw, int sh, int sstride,
                                                       int64_t sFrame, uint8_t* __restrict__ dst, int dw, int dh,
                                                       int dpitch, int64_t dFrame, const void* __restrict__ xtab,
-                                                      const void* __restrict__ ytab, double scaleX, double scaleY,
+                                                      const void* __restrict__ ytab, uint64_t scaleX, uint64_t scaleY,
                                                       int tp, int rowsMax, int tilesX, int tilesY, int nframes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
     const int t = threadIdx.x;
@@ -302,7 +302,7 @@ static int check_launch(const char* what) {
 static int launch_resize(bool area, int ntaps, const uint8_t* src, int sw, int sh, int sstride, int64_t sFrame, uint8_t* dst, int dw,
                          int dh, int dpitch, int64_t dFrame, const void* xt, const void* yt, int nframes,
                          hipStream_t st) {
-    const double scaleX = orb_resize_scale(sw, dw), scaleY = orb_resize_scale(sh, dh);
+    const uint64_t scaleX = orb_resize_scale_fx(sw, dw), scaleY = orb_resize_scale_fx(sh, dh);
     int tp = 0, rows = 0;
     orb_resize_tile_extent(sw, dw, scaleX, ORB_RS_TW, true, &tp);
     orb_resize_tile_extent(sh, dh, scaleY, ORB_RS_TH, false, &rows);

@@ -269,7 +269,7 @@ static void linear_taps(int ssize, int dsize, bool clampWeights, std::vector<Orb
 
 // Every tap of every resize tile must lie inside the source span the kernel stages for that tile.
 static int check_tile_spans(int ssize, int dsize, int tile, const OrbAreaTap* at, const OrbLinTap* lt) {
-    const double scale = orb_resize_scale(ssize, dsize);
+    const uint64_t scale = orb_resize_scale_fx(ssize, dsize);
     for (int d = 0; d < dsize; d++) {
         const int d0 = d / tile * tile, d1 = std::min(d0 + tile, dsize);
         int s0, s1, lo, hi;
@@ -304,8 +304,20 @@ static int compute_geom(orb_ctx* c, int w, int h) {
     g.iniTh = std::min(std::max(p.ini_th_fast, 0), 255);
     g.minTh = std::min(std::max(p.min_th_fast, 0), 255);
     g.quirks = p.quirks;
-    g.umaxPacked = 0;
-    for (int i = 0; i < 16; i++) g.umaxPacked |= (unsigned long long)(c->umax[i] & 15) << (4 * i);
+    for (int off = 0; off < 4; off++)
+        for (int r = 0; r < 31; r++)
+            for (int qi = 0; qi < 9; qi++) {
+                const int v = r - 15, lim = c->umax[v < 0 ? -v : v] & 15, u0 = 4 * (qi + 1) - off - 21;
+                uint32_t ones = 0u, weights = 0u;
+                for (int i = 0; i < 4; i++) {
+                    const int u = u0 + i;
+                    if (u < -lim || u > lim) continue;
+                    ones |= 1u << (8 * i);
+                    weights |= (uint32_t)(u + 32) << (8 * i);
+                }
+                g.icMask[off][r][qi][0] = ones;
+                g.icMask[off][r][qi][1] = weights;
+            }
     std::vector<OrbAreaTap> at;
     std::vector<OrbLinTap> lt;
     int64_t pyrOff = 0;

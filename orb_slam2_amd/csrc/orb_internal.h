@@ -46,8 +46,12 @@ struct OrbGeom {
     int64_t nodesPerFrame;        // sum of nodeCap
     int iniTh, minTh;
     unsigned quirks;
-    unsigned long long umaxPacked;  // 16 x 4 bits
     OrbLevel lv[ORB_MAX_LEVELS];
+    // IC_Angle byte weights (src/ORBextractor.cc:23-63) for the describe kernel, which reads the 31 patch rows as
+    // aligned dwords of its staged window: for window alignment off (0..3), patch row r (v = r - 15) and dword
+    // group qi (bytes u0 .. u0 + 3, u0 = 4 * (qi + 1) - off - 21), word 0 holds 1 in every byte with |u| <= umax[|v|]
+    // and word 1 holds u + 32 in those bytes (0 elsewhere).
+    uint32_t icMask[4][31][9][2];
 };
 
 struct OrbAreaTap {  // one destination index of the area resize: up to 4 source cells and their weights
@@ -62,7 +66,8 @@ struct OrbLinTap {   // one destination index of the linear resize
 // rectangle held in LDS.  orb_resize_span gives, per axis, a source index range that contains every
 // tap of destination indices [d0, d1): area taps lie in [floor(d0 * scale), floor(d1 * scale)],
 // linear taps in [floor(d0 * scale) - 1, floor(d1 * scale) + 2] once float rounding of the sample
-// position is allowed for.  The host checks the tap tables against it before the first launch.
+// position is allowed for; the span is at least that wide.  The host checks the tap tables against it
+// before the first launch.
 #define ORB_RS_TW 64
 #define ORB_RS_TH 32
 #define ORB_RS_TAP_BYTES (ORB_RS_TH * 32)   // the tile's vertical taps, staged in LDS
@@ -71,10 +76,17 @@ struct OrbLinTap {   // one destination index of the linear resize
 #else
 #define ORB_HD
 #endif
-static inline ORB_HD double orb_resize_scale(int ssize, int dsize) { return 1. / ((double)dsize / ssize); }
-static inline ORB_HD void orb_resize_span(int d0, int d1, double scale, int ssize, int* s0, int* s1) {
-    int lo = (int)(d0 * scale) - 1;  // operands are non-negative: truncation is floor
-    int hi = (int)(d1 * scale) + 2;
+// The source-to-destination ratio as cv::resize forms it, floored to 32.32 fixed point: (d * fx) >> 32 is
+// floor(d * scale) or one less, (d * (fx + 1)) >> 32 is floor(d * scale) or one more.  Whole-number arithmetic
+// on values that are the same for a whole workgroup, which the compiler keeps on the scalar unit (the
+// double-precision products it replaces ran on the vector unit in every lane).
+static inline uint64_t orb_resize_scale_fx(int ssize, int dsize) {
+    const double scale = 1. / ((double)dsize / ssize);
+    return (uint64_t)(scale * 4294967296.0);
+}
+static inline ORB_HD void orb_resize_span(int d0, int d1, uint64_t scaleFx, int ssize, int* s0, int* s1) {
+    int lo = (int)(((uint64_t)(unsigned)d0 * scaleFx) >> 32) - 1;
+    int hi = (int)(((uint64_t)(unsigned)d1 * (scaleFx + 1)) >> 32) + 2;
     if (lo < 0) lo = 0;
     if (hi > ssize - 1) hi = ssize - 1;
     *s0 = lo;
@@ -82,7 +94,7 @@ static inline ORB_HD void orb_resize_span(int d0, int d1, double scale, int ssiz
 }
 // Largest LDS extent any tile needs along one axis: bytes per row (dword-aligned start, whole dwords)
 // for the horizontal axis, rows for the vertical one.
-static inline void orb_resize_tile_extent(int ssize, int dsize, double scale, int tileSize, bool dwordAligned,
+static inline void orb_resize_tile_extent(int ssize, int dsize, uint64_t scale, int tileSize, bool dwordAligned,
                                           int* extent) {
     int best = 0;
     for (int d0 = 0; d0 < dsize; d0 += tileSize) {
