@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     static_assert(DESC_WAVES == 1, "the slot numbering assumes one wavefront per workgroup");
     int frameLocal;
     unsigned slotU;
-    if (!orb_xcd_map(blockIdx.x, (unsigned)outCapFrame, nframes, &frameLocal, &slotU)) return;
+    if (!orb_xcd_map(blockIdx.x, (unsigned)outCapFrame, g->outCapFrameMagic, nframes, &frameLocal, &slotU)) return;
     const int frame = frame0 + frameLocal;
     const int slot = (int)slotU;
     int level = 0;

@@ -160,7 +160,7 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
     const int cellsPerFrame = g->cellsPerFrame;
     int frameLocal;
     unsigned cellU;
-    if (!orb_xcd_map(blockIdx.x, (unsigned)cellsPerFrame, nframes, &frameLocal, &cellU)) return;
+    if (!orb_xcd_map(blockIdx.x, (unsigned)cellsPerFrame, g->cellsPerFrameMagic, nframes, &frameLocal, &cellU)) return;
     const int frame = frame0 + frameLocal;
     const int c = (int)cellU;
     const int64_t cellGlobal = (int64_t)frame * cellsPerFrame + c;
@@ -169,7 +169,7 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
         if (c >= g->lv[l].cellBase) level = l;
     const OrbLevel& L = g->lv[level];
     const int ci = c - L.cellBase;
-    const int i = ci / L.nCols, j = ci - i * L.nCols;
+    const int i = (int)orb_div((unsigned)ci, L.nColsMagic), j = ci - i * L.nCols;
 
     // Cell ROI and interior, src/ORBextractor.cc:825-844 (note the 3 / 6 asymmetry of the skip tests).
     const int iniY = ORB_BORDER + i * L.hCell, iniX = ORB_BORDER + j * L.wCell;
@@ -209,8 +209,8 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
         // lane = (row within a pass, dword); a pass covers 64 / nd rows.  All of a lane's loads are issued
         // before the first one is awaited: one after the other they would make up most of the wavefront's life.
         constexpr int RPP_MIN = 64 / (TILE_PITCH / 4), MAX_PASSES = (TILE_ROWS + RPP_MIN - 1) / RPP_MIN;
-        const int rpp = 64 / nd;
-        const int rr = lane / nd, d = lane - rr * nd;
+        const int rpp = orb_div_small(64, nd);
+        const int rr = orb_div_small(lane, nd), d = lane - rr * nd;
         if (rr < rpp) {
             const uint8_t* src = img + (int64_t)(Y0 - 3 + rr) * pitch + xa + 4 * d;
             uint32_t* dst = (uint32_t*)&tile[rr * TILE_PITCH + 4 * d];

@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
                                                       int64_t sFrame, uint8_t* __restrict__ dst, int dw, int dh,
                                                       int dpitch, int64_t dFrame, const void* __restrict__ xtab,
                                                       const void* __restrict__ ytab, uint64_t scaleX, uint64_t scaleY,
-                                                      int tp, int rowsMax, int tilesX, int tilesY, int nframes) {
+                                                      int tp, int rowsMax, int tilesX, int tilesY, int nframes,
+                                                      unsigned tilesXMagic, unsigned tilesMagic) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
     const int t = threadIdx.x;
     RsTileCtx c;
@@ -150,8 +151,8 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
     // tiles of one frame on one XCD: neighbouring tiles share source rows and cache lines
     int frameLocal;
     unsigned tileId;
-    if (!orb_xcd_map(blockIdx.x, (unsigned)(tilesX * tilesY), nframes, &frameLocal, &tileId)) return;
-    const int bx = (int)(tileId % (unsigned)tilesX), by = (int)(tileId / (unsigned)tilesX);
+    if (!orb_xcd_map(blockIdx.x, (unsigned)(tilesX * tilesY), tilesMagic, nframes, &frameLocal, &tileId)) return;
+    const int by = (int)orb_div(tileId, tilesXMagic), bx = (int)tileId - by * tilesX;
     const int x0 = bx * ORB_RS_TW, x1 = min(x0 + ORB_RS_TW, dw);
     c.colValid = x0 + c.dx < dw;
     OrbAreaTap txa = {};
@@ -168,8 +169,8 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
     uint8_t* D = dst + (int64_t)frameLocal * dFrame;
     const bool aligned = (sstride & 3) == 0 && (((unsigned long long)S) & 3ull) == 0;
     // staging: thread = (row within a pass, dword); a pass covers 256 / nd rows (nd <= 256: checked by the launcher)
-    const int rpp = 256 / nd;
-    const int rr = t / nd, d = t - rr * nd;
+    const int rpp = orb_div_small(256, nd);
+    const int rr = orb_div_small(t, nd), d = t - rr * nd;
     const int col = c.sxa + 4 * d;
     const bool stager = rr < rpp;
     auto fetch = [&](int sy0, int r) -> uint32_t {
@@ -322,7 +323,8 @@ static int launch_resize(bool area, int ntaps, const uint8_t* src, int sw, int s
     const dim3 grid((unsigned)orb_xcd_grid(nframes, (int64_t)tilesX * tilesYwg));
 #define RS_LAUNCH(AREA_, NT_, PAIR_)                                                                                  \
     hipLaunchKernelGGL((k_resize_tiled<AREA_, NT_, PAIR_>), grid, dim3(256), lds, st, src, sw, sh, sstride, sFrame, dst, \
-                       dw, dh, dpitch, dFrame, xt, yt, scaleX, scaleY, tp, rows, tilesX, tilesYwg, nframes)
+                       dw, dh, dpitch, dFrame, xt, yt, scaleX, scaleY, tp, rows, tilesX, tilesYwg, nframes,       \
+                       orb_div_magic((uint32_t)tilesX), orb_div_magic((uint32_t)(tilesX * tilesYwg)))
     if (area && ntaps <= 3) {
         if (pair) RS_LAUNCH(true, 3, true); else RS_LAUNCH(true, 3, false);
     } else if (area) {

@@ -342,6 +342,7 @@ static int compute_geom(orb_ctx* c, int w, int h) {
                           h, L.w, L.h);
             return ORB_ERR_UNSUPPORTED;
         }
+        L.nColsMagic = orb_div_magic((uint32_t)L.nCols);
         L.wCell = (int)ceilf(width / L.nCols);
         L.hCell = (int)ceilf(height / L.nRows);
         if (L.wCell > 59 || L.hCell > 59) {
@@ -436,6 +437,8 @@ static int compute_geom(orb_ctx* c, int w, int h) {
     g.cellsPerFrame = cellBase;
     g.cellCap = cellCap;
     g.outCapFrame = outBase;
+    g.cellsPerFrameMagic = orb_div_magic((uint32_t)cellBase);
+    g.outCapFrameMagic = orb_div_magic((uint32_t)outBase);
     g.keysPerFrame = keyBase;
     g.nodesPerFrame = nodeBase;
     g.areaTapsMax = 1;

@@ -20,6 +20,7 @@ struct OrbLevel {
     int64_t off;                // byte offset of frame 0 inside the pyramid buffer (levels >= 1)
     int64_t frameStride;        // bytes between consecutive frames of this level
     int nCols, nRows, wCell, hCell;  // FAST cell grid, src/ORBextractor.cc:816-823
+    unsigned nColsMagic;             // orb_div_magic(nCols)
     int maxBorderX, maxBorderY;
     int cellBase;               // index of the level's first cell within a frame
     int nIni;                   // quadtree initial nodes, src/ORBextractor.cc:574
@@ -39,6 +40,7 @@ struct OrbLevel {
 struct OrbGeom {
     int nlevels, w, h;
     int cellsPerFrame, cellCap;   // cellCap: key slots per cell
+    unsigned cellsPerFrameMagic, outCapFrameMagic;  // orb_div_magic of cellsPerFrame and outCapFrame
     int maxCellW, maxCellH;       // largest FAST cell interior over all levels
     int areaTapsMax;              // most source cells any area-resize tap entry of the pyramid uses (per axis)
     int outCapFrame;              // sum of outCap
@@ -115,11 +117,30 @@ static inline void orb_resize_tile_extent(int ssize, int dsize, uint64_t scale, 
 // 8 frames use X = nframes: nothing is launched in vain, and a single frame spreads over all XCDs.
 #define ORB_XCDS 8
 static inline ORB_HD unsigned orb_xcd_lanes(int nframes) { return nframes < ORB_XCDS ? (unsigned)nframes : ORB_XCDS; }
+
+// Division by a number that is the same for the whole workgroup.  The scalar unit multiplies but does not
+// divide, and the general sequence runs on the vector unit in every lane; with magic = ceil(2^32 / d) from the
+// host, n / d = high word of n * magic, exact as long as n * d < 2^32 (every use here stays below 2^30).
+// d == 1 has no 32-bit magic and is passed as 0.
+static inline uint32_t orb_div_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d); }
 #ifdef __HIPCC__
-static __device__ __forceinline__ bool orb_xcd_map(unsigned b, unsigned perFrame, int nframes, int* frameLocal,
-                                                   unsigned* item) {
+static __device__ __forceinline__ unsigned orb_div(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
+// t / d for t < 256 and a divisor 1..256 that is only known on the device: multiplier 65536 / d + 1 from a table,
+// exact because t * d < 65536.
+struct OrbDiv16Table {
+    uint32_t m[257];
+    constexpr OrbDiv16Table() : m() {
+        for (int d = 1; d <= 256; d++) m[d] = 65536u / (uint32_t)d + 1u;
+    }
+};
+static __constant__ OrbDiv16Table c_orbDiv16 = OrbDiv16Table();
+static __device__ __forceinline__ int orb_div_small(int t, int d) { return (int)(__umul24((unsigned)t, c_orbDiv16.m[d]) >> 16); }
+
+static __device__ __forceinline__ bool orb_xcd_map(unsigned b, unsigned perFrame, unsigned perFrameMagic, int nframes,
+                                                   int* frameLocal, unsigned* item) {
     const unsigned X = orb_xcd_lanes(nframes);
-    const unsigned j = b / X, k = j / perFrame;
+    const unsigned j = X == ORB_XCDS ? b >> 3 : b / X;  // (fewer than eight frames: a single-frame call, not a batch)
+    const unsigned k = orb_div(j, perFrameMagic);
     *item = j - k * perFrame;
     *frameLocal = (int)(b - j * X + X * k);
     return *frameLocal < nframes;
