@@ -25,6 +25,7 @@ struct QtLaunch {
     int ldsKeys;          // sort entries the LDS block holds
     int binBits;          // key-sort buckets = 2^binBits
     int regionInts;       // ints behind the keys: bucket arrays, then node scratch
+    unsigned nframesMagic;  // orb_div_magic(frames of the launch)
 };
 
 // Sort, distribute, select and emit one level.  Inlined once per memory placement so that the
@@ -48,12 +49,11 @@ static __device__ __forceinline__ int qt_level(const OrbGeom* g, const OrbLevel&
         count = L.outCap;
     }
     qt_select_all(sorted, list, count, w.scanA, sh);
-    const int cellCap = g->cellCap;
     for (int i = t; i < count; i += T) {
         const int rank = w.scanA[i];
         const uint32_t key = levelCellKeys[rank];  // rank = cell * cellCap + position inside the cell
-        const int cell = rank / cellCap;
-        const int ci = cell / L.nCols, cj = cell - ci * L.nCols;
+        const int cell = (int)orb_div((unsigned)rank, g->cellCapMagic);
+        const int ci = (int)orb_div((unsigned)cell, L.nColsMagic), cj = cell - ci * L.nCols;
         const int x = 3 + cj * L.wCell + (int)(key & 0xff);  // relative to the 16-pixel border, src/ORBextractor.cc:864-865
         const int y = 3 + ci * L.hCell + (int)((key >> 8) & 0xff);
         selXY[i] = (uint32_t)x | ((uint32_t)y << 16);
@@ -78,7 +78,8 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __re
     const QtBins bins = {s_region, s_region + (1 << q.binBits) + 1, q.binBits};
     const int nlevels = g->nlevels;
     // level-major launch order: the levels with the most keys (the longest-running workgroups) start first
-    const int level = q.level0 + blockIdx.x / nframes, frame = frame0 + blockIdx.x % nframes;
+    const int levelLocal = (int)orb_div(blockIdx.x, q.nframesMagic);
+    const int level = q.level0 + levelLocal, frame = frame0 + (int)blockIdx.x - levelLocal * nframes;
     const OrbLevel& L = g->lv[level];
     const int t = threadIdx.x, T = (int)blockDim.x;
     unsigned long long* sortedG = sortBuf + ((int64_t)frame * g->keysPerFrame + L.keyBase) * 2;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __re
             }
             const int k = r - off[lo], cell = c0 + lo;
             const uint32_t key = lck[(int64_t)cell * cellCap + k];
-            const int ci = cell / L.nCols, cj = cell - ci * L.nCols;
+            const int ci = (int)orb_div((unsigned)cell, L.nColsMagic), cj = cell - ci * L.nCols;
             const int x = 3 + cj * L.wCell + (int)(key & 0xff);  // relative to the 16-pixel border, as :864-865
             const int y = 3 + ci * L.hCell + (int)((key >> 8) & 0xff);
             if (n + r < L.keyCap)
@@ -212,6 +213,7 @@ int orb_launch_quadtree(const OrbBatch& b) {
             if (q2.ldsKeys > 0 && block_bytes(q2) <= room) q = q2;
         }
     }
+    q.nframesMagic = orb_div_magic((uint32_t)b.nframes);
     const size_t lds = (size_t)q.ldsKeys * 8 + (size_t)q.regionInts * 4;
     hipLaunchKernelGGL(k_quadtree, dim3(b.nframes * q.nlevels), dim3(threads), lds, (hipStream_t)b.stream, b.d_geom, q,
                        b.frame0, b.nframes, b.d_cellKeys, b.d_cellCount, b.d_sort, b.d_nodes, b.d_ints, b.d_selXY, b.d_selScore, b.d_levelCount,

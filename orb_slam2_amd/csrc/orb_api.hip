@@ -439,6 +439,7 @@ static int compute_geom(orb_ctx* c, int w, int h) {
     g.outCapFrame = outBase;
     g.cellsPerFrameMagic = orb_div_magic((uint32_t)cellBase);
     g.outCapFrameMagic = orb_div_magic((uint32_t)outBase);
+    g.cellCapMagic = orb_div_magic((uint32_t)cellCap);
     g.keysPerFrame = keyBase;
     g.nodesPerFrame = nodeBase;
     g.areaTapsMax = 1;

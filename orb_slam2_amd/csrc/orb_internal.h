@@ -40,7 +40,7 @@ struct OrbLevel {
 struct OrbGeom {
     int nlevels, w, h;
     int cellsPerFrame, cellCap;   // cellCap: key slots per cell
-    unsigned cellsPerFrameMagic, outCapFrameMagic;  // orb_div_magic of cellsPerFrame and outCapFrame
+    unsigned cellsPerFrameMagic, outCapFrameMagic, cellCapMagic;  // orb_div_magic of cellsPerFrame, outCapFrame, cellCap
     int maxCellW, maxCellH;       // largest FAST cell interior over all levels
     int areaTapsMax;              // most source cells any area-resize tap entry of the pyramid uses (per axis)
     int outCapFrame;              // sum of outCap

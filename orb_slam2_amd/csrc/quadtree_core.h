@@ -26,6 +26,7 @@
 #define QT_BARRIER() ((void)0)
 #define QT_TID 0
 #define QT_NT 1
+#define QT_NT_SHIFT 0
 #define QT_FDIV(a, b) ((a) / (b))
 #define QT_ATOMIC_ADD(p, v) qt_host_fetch_add((p), (v))
 #define QT_ATOMIC_MAX32(p, v) (*(p) = (*(p) > (v)) ? *(p) : (v))
@@ -39,6 +40,7 @@ static inline int qt_host_fetch_add(int* p, int v) {
 #define QT_BARRIER() __syncthreads()
 #define QT_TID ((int)threadIdx.x)
 #define QT_NT ((int)blockDim.x)
+#define QT_NT_SHIFT (blockDim.x == 1024 ? 10 : 8)  // the kernel runs with 256 or 1024 threads: a shift, not a division
 #define QT_FDIV(a, b) __fdiv_rn((a), (b))
 #define QT_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #define QT_ATOMIC_MAX32(p, v) atomicMax((p), (v))
@@ -161,7 +163,7 @@ QT_FN int qt_lower_bound(const unsigned long long* s, int lo, int hi, uint32_t k
 // each wavefront with shuffles and across wavefronts through LDS.
 QT_FN void qt_scan(int* a, int n, QtShared* sh) {
     const int T = QT_NT, t = QT_TID;
-    const int chunk = (n + T - 1) / T;
+    const int chunk = (n + T - 1) >> QT_NT_SHIFT;
     const int b = t * chunk, e = (b + chunk < n) ? b + chunk : n;
     int s = 0;
     for (int i = b; i < e; i++) s += a[i];
@@ -204,7 +206,7 @@ QT_FN void qt_scan(int* a, int n, QtShared* sh) {
 // the data, one shuffle ladder and two barriers.  a[n], b[n], c[n] receive the totals.
 QT_FN void qt_scan3(int* a, int* b, int* c, int n, QtShared* sh) {
     const int T = QT_NT, t = QT_TID;
-    const int chunk = (n + T - 1) / T;
+    const int chunk = (n + T - 1) >> QT_NT_SHIFT;
     const int lo = t * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
     unsigned long long s = 0ull;
     for (int i = lo; i < hi; i++)
@@ -504,10 +506,11 @@ QT_FN void qt_sort(unsigned long long* a, int n) {
     int np2 = 1;
     while (np2 < n) np2 <<= 1;
     const int pairs = np2 >> 1;
-    for (int k = 2; k <= np2; k <<= 1) {
+    // (k, hk and jj are powers of two: block and offset by shift and mask)
+    for (int k = 2, lk = 1; k <= np2; k <<= 1, lk++) {
         const int hk = k >> 1;
         for (int p = t; p < pairs; p += T) {
-            const int blk = p / hk, o = p - blk * hk;
+            const int blk = p >> (lk - 1), o = p & (hk - 1);
             const int i = blk * k + o, j = blk * k + k - 1 - o;
             if (j < n) {
                 const unsigned long long x = a[i], y = a[j];
@@ -515,9 +518,9 @@ QT_FN void qt_sort(unsigned long long* a, int n) {
             }
         }
         QT_BARRIER();
-        for (int jj = k >> 2; jj > 0; jj >>= 1) {
+        for (int jj = k >> 2, lj = lk - 2; jj > 0; jj >>= 1, lj--) {
             for (int p = t; p < pairs; p += T) {
-                const int blk = p / jj, o = p - blk * jj;
+                const int blk = p >> lj, o = p & (jj - 1);
                 const int i = blk * 2 * jj + o, j = i + jj;
                 if (j < n) {
                     const unsigned long long x = a[i], y = a[j];
