@@ -169,7 +169,7 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
         if (c >= g->lv[l].cellBase) level = l;
     const OrbLevel& L = g->lv[level];
     const int ci = c - L.cellBase;
-    const int i = (int)orb_div((unsigned)ci, L.nColsMagic), j = ci - i * L.nCols;
+    const int i = (int)orb_div((unsigned)ci, (unsigned)L.nCols, L.nColsMagic), j = ci - i * L.nCols;
 
     // Cell ROI and interior, src/ORBextractor.cc:825-844 (note the 3 / 6 asymmetry of the skip tests).
     const int iniY = ORB_BORDER + i * L.hCell, iniX = ORB_BORDER + j * L.wCell;

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
     int frameLocal;
     unsigned tileId;
     if (!orb_xcd_map(blockIdx.x, (unsigned)(tilesX * tilesY), tilesMagic, nframes, &frameLocal, &tileId)) return;
-    const int by = (int)orb_div(tileId, tilesXMagic), bx = (int)tileId - by * tilesX;
+    const int by = (int)orb_div(tileId, (unsigned)tilesX, tilesXMagic), bx = (int)tileId - by * tilesX;
     const int x0 = bx * ORB_RS_TW, x1 = min(x0 + ORB_RS_TW, dw);
     c.colValid = x0 + c.dx < dw;
     OrbAreaTap txa = {};
@@ -324,7 +324,8 @@ static int launch_resize(bool area, int ntaps, const uint8_t* src, int sw, int s
 #define RS_LAUNCH(AREA_, NT_, PAIR_)                                                                                  \
     hipLaunchKernelGGL((k_resize_tiled<AREA_, NT_, PAIR_>), grid, dim3(256), lds, st, src, sw, sh, sstride, sFrame, dst, \
                        dw, dh, dpitch, dFrame, xt, yt, scaleX, scaleY, tp, rows, tilesX, tilesYwg, nframes,       \
-                       orb_div_magic((uint32_t)tilesX), orb_div_magic((uint32_t)(tilesX * tilesYwg)))
+                       orb_div_magic((uint32_t)tilesX, (uint64_t)tilesX * tilesYwg),                               \
+                       orb_div_magic((uint32_t)(tilesX * tilesYwg), (uint64_t)grid.x))
     if (area && ntaps <= 3) {
         if (pair) RS_LAUNCH(true, 3, true); else RS_LAUNCH(true, 3, false);
     } else if (area) {

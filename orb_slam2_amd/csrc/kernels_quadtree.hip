@@ -52,8 +52,8 @@ static __device__ __forceinline__ int qt_level(const OrbGeom* g, const OrbLevel&
     for (int i = t; i < count; i += T) {
         const int rank = w.scanA[i];
         const uint32_t key = levelCellKeys[rank];  // rank = cell * cellCap + position inside the cell
-        const int cell = (int)orb_div((unsigned)rank, g->cellCapMagic);
-        const int ci = (int)orb_div((unsigned)cell, L.nColsMagic), cj = cell - ci * L.nCols;
+        const int cell = (int)orb_div((unsigned)rank, (unsigned)g->cellCap, g->cellCapMagic);
+        const int ci = (int)orb_div((unsigned)cell, (unsigned)L.nCols, L.nColsMagic), cj = cell - ci * L.nCols;
         const int x = 3 + cj * L.wCell + (int)(key & 0xff);  // relative to the 16-pixel border, src/ORBextractor.cc:864-865
         const int y = 3 + ci * L.hCell + (int)((key >> 8) & 0xff);
         selXY[i] = (uint32_t)x | ((uint32_t)y << 16);
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __re
     const QtBins bins = {s_region, s_region + (1 << q.binBits) + 1, q.binBits};
     const int nlevels = g->nlevels;
     // level-major launch order: the levels with the most keys (the longest-running workgroups) start first
-    const int levelLocal = (int)orb_div(blockIdx.x, q.nframesMagic);
+    const int levelLocal = (int)orb_div(blockIdx.x, (unsigned)nframes, q.nframesMagic);
     const int level = q.level0 + levelLocal, frame = frame0 + (int)blockIdx.x - levelLocal * nframes;
     const OrbLevel& L = g->lv[level];
     const int t = threadIdx.x, T = (int)blockDim.x;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __re
             }
             const int k = r - off[lo], cell = c0 + lo;
             const uint32_t key = lck[(int64_t)cell * cellCap + k];
-            const int ci = (int)orb_div((unsigned)cell, L.nColsMagic), cj = cell - ci * L.nCols;
+            const int ci = (int)orb_div((unsigned)cell, (unsigned)L.nCols, L.nColsMagic), cj = cell - ci * L.nCols;
             const int x = 3 + cj * L.wCell + (int)(key & 0xff);  // relative to the 16-pixel border, as :864-865
             const int y = 3 + ci * L.hCell + (int)((key >> 8) & 0xff);
             if (n + r < L.keyCap)
@@ -213,7 +213,7 @@ int orb_launch_quadtree(const OrbBatch& b) {
             if (q2.ldsKeys > 0 && block_bytes(q2) <= room) q = q2;
         }
     }
-    q.nframesMagic = orb_div_magic((uint32_t)b.nframes);
+    q.nframesMagic = orb_div_magic((uint32_t)b.nframes, (uint64_t)b.nframes * q.nlevels);
     const size_t lds = (size_t)q.ldsKeys * 8 + (size_t)q.regionInts * 4;
     hipLaunchKernelGGL(k_quadtree, dim3(b.nframes * q.nlevels), dim3(threads), lds, (hipStream_t)b.stream, b.d_geom, q,
                        b.frame0, b.nframes, b.d_cellKeys, b.d_cellCount, b.d_sort, b.d_nodes, b.d_ints, b.d_selXY, b.d_selScore, b.d_levelCount,

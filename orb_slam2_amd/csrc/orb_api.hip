@@ -342,7 +342,7 @@ static int compute_geom(orb_ctx* c, int w, int h) {
                           h, L.w, L.h);
             return ORB_ERR_UNSUPPORTED;
         }
-        L.nColsMagic = orb_div_magic((uint32_t)L.nCols);
+        L.nColsMagic = orb_div_magic((uint32_t)L.nCols, (uint64_t)L.nCols * L.nRows);
         L.wCell = (int)ceilf(width / L.nCols);
         L.hCell = (int)ceilf(height / L.nRows);
         if (L.wCell > 59 || L.hCell > 59) {
@@ -437,9 +437,14 @@ static int compute_geom(orb_ctx* c, int w, int h) {
     g.cellsPerFrame = cellBase;
     g.cellCap = cellCap;
     g.outCapFrame = outBase;
-    g.cellsPerFrameMagic = orb_div_magic((uint32_t)cellBase);
-    g.outCapFrameMagic = orb_div_magic((uint32_t)outBase);
-    g.cellCapMagic = orb_div_magic((uint32_t)cellCap);
+    // dividends: workgroup number / 8 (frames go to the eight XCD lanes in turn), key rank within a level
+    const uint64_t framesPerLane = ((uint64_t)std::max(p.max_batch, 1) + ORB_XCDS - 1) / ORB_XCDS;
+    uint64_t maxRank = 0;
+    for (int l = 0; l < g.nlevels; l++)
+        maxRank = std::max<uint64_t>(maxRank, (uint64_t)g.lv[l].nCols * g.lv[l].nRows * cellCap);
+    g.cellsPerFrameMagic = orb_div_magic((uint32_t)cellBase, framesPerLane * cellBase);
+    g.outCapFrameMagic = orb_div_magic((uint32_t)outBase, framesPerLane * outBase);
+    g.cellCapMagic = orb_div_magic((uint32_t)cellCap, maxRank);
     g.keysPerFrame = keyBase;
     g.nodesPerFrame = nodeBase;
     g.areaTapsMax = 1;

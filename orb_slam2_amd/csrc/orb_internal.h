@@ -1,6 +1,7 @@
 // Internal declarations shared by the host side of liborbhip and its kernels.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/orb_hip.h"
 
@@ -120,11 +121,18 @@ static inline ORB_HD unsigned orb_xcd_lanes(int nframes) { return nframes < ORB_
 
 // Division by a number that is the same for the whole workgroup.  The scalar unit multiplies but does not
 // divide, and the general sequence runs on the vector unit in every lane; with magic = ceil(2^32 / d) from the
-// host, n / d = high word of n * magic, exact as long as n * d < 2^32 (every use here stays below 2^30).
-// d == 1 has no 32-bit magic and is passed as 0.
-static inline uint32_t orb_div_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d); }
+// host, n / d = high word of n * magic, exact as long as n * d < 2^32.  The host knows the largest dividend
+// (nMax) of each use; where the bound does not hold, and for d == 1, it passes magic 0 and the kernel divides
+// the ordinary way.
+static inline uint32_t orb_div_magic(uint32_t d, uint64_t nMax) {
+    if (d <= 1 || nMax * d >= 0x100000000ull) return 0u;
+    if (getenv("ORBHIP_PLAIN_DIVISION")) return 0u;  // lets the tests run the ordinary-division path
+    return (uint32_t)((0x100000000ull + d - 1) / d);
+}
 #ifdef __HIPCC__
-static __device__ __forceinline__ unsigned orb_div(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
+static __device__ __forceinline__ unsigned orb_div(unsigned n, unsigned d, unsigned magic) {
+    return magic ? __umulhi(n, magic) : n / d;
+}
 // t / d for t < 256 and a divisor 1..256 that is only known on the device: multiplier 65536 / d + 1 from a table,
 // exact because t * d < 65536.
 struct OrbDiv16Table {
@@ -140,7 +148,7 @@ static __device__ __forceinline__ bool orb_xcd_map(unsigned b, unsigned perFrame
                                                    int* frameLocal, unsigned* item) {
     const unsigned X = orb_xcd_lanes(nframes);
     const unsigned j = X == ORB_XCDS ? b >> 3 : b / X;  // (fewer than eight frames: a single-frame call, not a batch)
-    const unsigned k = orb_div(j, perFrameMagic);
+    const unsigned k = orb_div(j, perFrame, perFrameMagic);
     *item = j - k * perFrame;
     *frameLocal = (int)(b - j * X + X * k);
     return *frameLocal < nframes;

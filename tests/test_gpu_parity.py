@@ -182,6 +182,26 @@ def test_extract_batch_threaded_staging(hip, oracle):
     c.close()
 
 
+def test_extract_with_plain_division(hip, oracle, monkeypatch):
+    """The kernels divide by workgroup-uniform numbers through multipliers the host prepares, and fall back to
+    ordinary division where a multiplier would not be exact; ORBHIP_PLAIN_DIVISION forces the fallback."""
+    monkeypatch.setenv("ORBHIP_PLAIN_DIVISION", "1")
+    n, w, h = 11, 400, 300
+    c = _ctx(hip, "fork", 700, 7, w, h, batch=n)
+    e = oracle.Extractor(700, 1.2, 7, 20, 7, PRESETS["fork"])
+    imgs = [synth_scene(w, h, frame_seed(2, 80 + f)) for f in range(n)]
+    res = c.extract_batch(imgs)
+    for f in range(n):
+        ko, do = e.extract(imgs[f])
+        assert_kps_equal(res[f][0], ko, "frame %d" % f)
+        np.testing.assert_array_equal(res[f][1], do)
+    kg, dg = c.extract(imgs[3])
+    ko, do = e.extract(imgs[3])
+    assert_kps_equal(kg, ko, "single frame")
+    np.testing.assert_array_equal(dg, do)
+    c.close()
+
+
 def test_extract_after_sparse_frames(hip, oracle):
     """The quadtree kernel sizes its LDS block from the key counts of earlier batches; a frame with
     far more keys than any before must come out the same (its levels run from global memory)."""
