@@ -5,15 +5,20 @@
 // The scan applies the best / second-best rule of src/ORBmatcher.cc:53-76 to
 // every database row in index order.
 //
-// Mapping: one lane holds QPL query descriptors in registers (8 VGPRs each);
-// database rows are wave-uniform, so they arrive through scalar loads into
-// SGPRs and every comparison is VGPR x SGPR.  Rows are taken GROUP at a time;
-// the top-2 state (best distance, best row, second distance per query) is only
-// touched when some lane of the wave saw a distance below its current second
-// best, which for all but the first few thousand rows of a chunk is rare.
-// The database is cut into chunks along blockIdx.y so that a shard fills the
-// chip; per-chunk results are packed as best << 48 | second << 32 | global row
-// and combined by the same merge kernel that combines the shards of several GPUs.
+// Mapping: one lane holds QPL query descriptors in registers (8 VGPRs each).
+// A workgroup copies TR database rows per tile into LDS with one coalesced
+// 16-byte load per thread (two tiles in flight) and every wavefront reads the
+// rows back as broadcast ds_read_b128 (all lanes the same address, no bank
+// conflict), so a comparison is VGPR x VGPR and the row traffic rides the
+// vector memory path.  (Rows streamed through scalar loads instead stall on the
+// scalar data cache, which sustains about one 64-byte miss per ~130 cycles per
+// CU.)  Rows are taken GROUP at a time; the top-2 state (best distance, best
+// row, second distance per query) is only touched when some lane of the wave
+// saw a distance below its current second best, which for all but the first few
+// thousand rows of a chunk is rare.  The database is cut into chunks along
+// blockIdx.y so that a shard fills the chip; per-chunk results are packed as
+// best << 48 | second << 32 | global row and combined by the same merge kernel
+// that combines the shards of several GPUs.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -39,9 +44,7 @@ struct orb_bf {
     size_t outBytes = 0;
     hipStream_t stream = nullptr;
     int residentBlocks = 0;  // workgroups of the scan kernel the device holds at once
-    int variant = -1;
 };
-
 
 // popcount(x) + acc in one instruction; written as asm because the compiler
 // otherwise splits the chain into bcnt(x, 0) plus separate three-operand adds.
@@ -51,7 +54,7 @@ static __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
     return r;
 }
 
-struct Row256 {  // one database row, wave-uniform (lives in SGPRs)
+struct Row256 {  // one database row, the same for every lane of the wavefront
     uint4 lo, hi;
 };
 
@@ -88,7 +91,7 @@ static __device__ __forceinline__ void top2_update(uint32_t d, uint32_t row, uin
 }
 
 // One group of GROUP rows against the lane's QPL queries.
-template <int QPL, int GROUP, bool MINRED>
+template <int QPL, int GROUP>
 static __device__ __forceinline__ void bf_group(const uint32_t (&qv)[QPL][8], const Row256 (&rw)[GROUP], uint32_t rowBase,
                                                 uint32_t (&bd)[QPL], uint32_t (&bi)[QPL], uint32_t (&sd)[QPL]) {
     uint32_t d[GROUP][QPL];
@@ -98,17 +101,15 @@ static __device__ __forceinline__ void bf_group(const uint32_t (&qv)[QPL][8], co
 #pragma unroll
         for (int j = 0; j < QPL; j++) {
             d[g][j] = hamming256(qv[j], rw[g]);
-            if (!MINRED) any |= d[g][j] < sd[j];
         }
     }
-    if (MINRED) {
+    // one compare per query against the smallest distance of the group
 #pragma unroll
-        for (int j = 0; j < QPL; j++) {
-            uint32_t m = d[0][j];
+    for (int j = 0; j < QPL; j++) {
+        uint32_t m = d[0][j];
 #pragma unroll
-            for (int g = 1; g < GROUP; g++) m = min(m, d[g][j]);
-            any |= m < sd[j];
-        }
+        for (int g = 1; g < GROUP; g++) m = min(m, d[g][j]);
+        any |= m < sd[j];
     }
     if (__builtin_amdgcn_ballot_w64(any)) {
 #pragma unroll
@@ -119,89 +120,6 @@ static __device__ __forceinline__ void bf_group(const uint32_t (&qv)[QPL][8], co
     }
 }
 
-template <int QPL, int GROUP, bool PREFETCH, bool MINRED>
-__global__ __launch_bounds__(256) void k_bf_top2(const uint32_t* __restrict__ q, int nq,
-                                                 const uint32_t* __restrict__ db, long long nd,
-                                                 long long rowsPerChunk, long long globalBase,
-                                                 unsigned long long* __restrict__ partial) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long qb = ((long long)blockIdx.x * 4 + wave) * (64 * QPL);
-    if (qb >= nq) return;
-    uint32_t qv[QPL][8];
-    uint32_t bd[QPL], sd[QPL], bi[QPL];
-#pragma unroll
-    for (int j = 0; j < QPL; j++) {
-        long long qi = qb + j * 64 + lane;
-        if (qi >= nq) qi = nq - 1;  // tail lanes compute on a valid row and are not written back
-        const uint4* p = (const uint4*)(q + qi * 8);
-        const uint4 lo = p[0], hi = p[1];
-        qv[j][0] = lo.x; qv[j][1] = lo.y; qv[j][2] = lo.z; qv[j][3] = lo.w;
-        qv[j][4] = hi.x; qv[j][5] = hi.y; qv[j][6] = hi.z; qv[j][7] = hi.w;
-        bd[j] = BF_NONE;
-        sd[j] = BF_NONE;
-        bi[j] = 0xFFFFFFFFu;
-    }
-    const long long r0 = (long long)blockIdx.y * rowsPerChunk;
-    const long long r1 = (r0 + rowsPerChunk < nd) ? r0 + rowsPerChunk : nd;
-    long long r = r0;
-    if (PREFETCH) {
-        // two row buffers: the scalar loads of the next group are in flight while this group is compared
-        Row256 A[GROUP], B[GROUP];
-        if (r + GROUP <= r1) {
-#pragma unroll
-            for (int g = 0; g < GROUP; g++) A[g] = load_row(db + (r + g) * 8);
-        }
-        while (r + 2 * GROUP <= r1) {
-#pragma unroll
-            for (int g = 0; g < GROUP; g++) B[g] = load_row(db + (r + GROUP + g) * 8);
-            bf_group<QPL, GROUP, MINRED>(qv, A, (uint32_t)(r - r0), bd, bi, sd);
-            r += GROUP;
-            if (r + 2 * GROUP <= r1) {
-#pragma unroll
-                for (int g = 0; g < GROUP; g++) A[g] = load_row(db + (r + GROUP + g) * 8);
-                bf_group<QPL, GROUP, MINRED>(qv, B, (uint32_t)(r - r0), bd, bi, sd);
-                r += GROUP;
-            } else {
-#pragma unroll
-                for (int g = 0; g < GROUP; g++) A[g] = B[g];
-            }
-        }
-        if (r + GROUP <= r1) {
-            bf_group<QPL, GROUP, MINRED>(qv, A, (uint32_t)(r - r0), bd, bi, sd);
-            r += GROUP;
-        }
-    } else {
-        for (; r + GROUP <= r1; r += GROUP) {
-            Row256 rw[GROUP];
-#pragma unroll
-            for (int g = 0; g < GROUP; g++) rw[g] = load_row(db + (r + g) * 8);  // wave-uniform address: scalar loads
-            bf_group<QPL, GROUP, MINRED>(qv, rw, (uint32_t)(r - r0), bd, bi, sd);
-        }
-    }
-    for (; r < r1; r++) {
-        const Row256 row = load_row(db + r * 8);
-#pragma unroll
-        for (int j = 0; j < QPL; j++) top2_update(hamming256(qv[j], row), (uint32_t)(r - r0), bd[j], bi[j], sd[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < QPL; j++) {
-        const long long qi = qb + j * 64 + lane;
-        if (qi < nq) {
-            const unsigned long long idx =
-                (bd[j] == BF_NONE) ? 0xFFFFFFFFull : (unsigned long long)(globalBase + r0 + bi[j]) & 0xFFFFFFFFull;
-            partial[(long long)blockIdx.y * nq + qi] =
-                ((unsigned long long)bd[j] << 48) | ((unsigned long long)sd[j] << 32) | idx;
-        }
-    }
-}
-
-// Variant that stages database rows in LDS: the scalar data cache sustains only
-// about one 64-byte miss per ~130 cycles per CU, which caps a scan that streams
-// its rows through scalar loads at under half the VALU rate.  Here the workgroup
-// copies TR rows per tile into LDS with one coalesced 16-byte load per thread
-// (two tiles in flight), and every wave reads the rows back as broadcast
-// ds_read_b128 (all lanes the same address: conflict-free), so the compare is
-// VGPR x VGPR and the row traffic rides the vector memory path.
 template <int QPL, int GROUP, int TR>
 __global__ __launch_bounds__(256) void k_bf_top2_lds(const uint32_t* __restrict__ q, int nq,
                                                      const uint32_t* __restrict__ db, long long nd,
@@ -262,7 +180,7 @@ __global__ __launch_bounds__(256) void k_bf_top2_lds(const uint32_t* __restrict_
                 Row256 rw[GROUP];
 #pragma unroll
                 for (int g = 0; g < GROUP; g++) rw[g] = load_row(tile + (r + g) * 8);
-                bf_group<QPL, GROUP, true>(qv, rw, (uint32_t)(t - r0) + r, bd, bi, sd);
+                bf_group<QPL, GROUP>(qv, rw, (uint32_t)(t - r0) + r, bd, bi, sd);
             }
             for (; r < rowsHere; r++) {
                 const Row256 row = load_row(tile + r * 8);
@@ -288,34 +206,12 @@ __global__ __launch_bounds__(256) void k_bf_top2_lds(const uint32_t* __restrict_
     }
 }
 
+// Tuning of the scan kernel (measured over 2..8 queries per lane, groups of 2..8 rows, tiles of 128 / 256 rows).
+#define BF_QPL 2
+#define BF_GROUP 4
+#define BF_TILE_ROWS 128
 typedef void (*bf_kernel_t)(const uint32_t*, int, const uint32_t*, long long, long long, long long, unsigned long long*);
-struct BfVariant {
-    const char* name;
-    bf_kernel_t fn;
-    int qpl, group;
-};
-static const BfVariant kBfVariants[] = {
-    {"q4g4", k_bf_top2<4, 4, false, false>, 4, 4},
-    {"q4g4p", k_bf_top2<4, 4, true, false>, 4, 4},
-    {"q4g4m", k_bf_top2<4, 4, false, true>, 4, 4},
-    {"q4g4pm", k_bf_top2<4, 4, true, true>, 4, 4},
-    {"q8g2", k_bf_top2<8, 2, false, false>, 8, 2},
-    {"q8g2pm", k_bf_top2<8, 2, true, true>, 8, 2},
-    {"q8g4m", k_bf_top2<8, 4, false, true>, 8, 4},
-    {"q4g8m", k_bf_top2<4, 8, false, true>, 4, 8},
-    {"q2g8m", k_bf_top2<2, 8, false, true>, 2, 8},
-    {"q2g8pm", k_bf_top2<2, 8, true, true>, 2, 8},
-    {"q6g4pm", k_bf_top2<6, 4, true, true>, 6, 4},
-    {"L_q4g4t128", k_bf_top2_lds<4, 4, 128>, 4, 4},
-    {"L_q4g2t128", k_bf_top2_lds<4, 2, 128>, 4, 2},
-    {"L_q4g4t256", k_bf_top2_lds<4, 4, 256>, 4, 4},
-    {"L_q8g2t128", k_bf_top2_lds<8, 2, 128>, 8, 2},
-    {"L_q8g4t256", k_bf_top2_lds<8, 4, 256>, 8, 4},
-    {"L_q6g2t128", k_bf_top2_lds<6, 2, 128>, 6, 2},
-    {"L_q2g4t128", k_bf_top2_lds<2, 4, 128>, 2, 4},
-    {"L_q4g8t256", k_bf_top2_lds<4, 8, 256>, 4, 8},
-};
-#define BF_DEFAULT_VARIANT 17  // L_q2g4t128
+static const bf_kernel_t k_bf_scan = k_bf_top2_lds<BF_QPL, BF_GROUP, BF_TILE_ROWS>;
 
 // Combine nshards packed candidates per query.  Inserting every shard's best
 // (distance, row) and second distance into one running top-2 equals scanning
@@ -360,9 +256,17 @@ extern "C" int orb_bf_create(int device, orb_bf** out) {
         return ORB_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(device));
+    // everything a query needs besides buffers is settled here, so that the query entry points make no
+    // runtime call other than launches (and, for the growing variants, hipMalloc)
+    int perCu = 0, cus = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_bf_scan, 256, 0));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     orb_bf* bf = new orb_bf();
     bf->device = device;
-    HIP_TRY(hipStreamCreateWithFlags(&bf->stream, hipStreamNonBlocking));
+    bf->stream = st;
+    bf->residentBlocks = std::max(1, perCu) * std::max(1, cus);
     *out = bf;
     return ORB_OK;
 }
@@ -448,9 +352,10 @@ extern "C" int orb_bf_set_database(orb_bf* bf, const uint8_t* db, int64_t n, int
 // so that the last round is (almost) full instead of leaving most of the chip
 // idle behind a few stragglers, while chunks stay long enough that the first
 // rows of a chunk (which update the top-2 state often) are a small share.
-static int bf_chunks(int nq, int64_t nd, int resident, int qpl, int group, long long* rowsPerChunk) {
+static int bf_chunks(int nq, int64_t nd, int resident, int qpl, int group, long long chunkLimit,
+                     long long* rowsPerChunk) {
     const long long qBlocks = (nq + 256 * qpl - 1) / (256 * qpl);
-    const long long maxChunks = std::max<long long>(1, std::min<long long>(nd / 8192, 4096));
+    const long long maxChunks = std::max<long long>(1, std::min<long long>(std::min<long long>(nd / 8192, 4096), chunkLimit));
     long long best = 1;
     double bestEff = -1.0;
     if (resident < 1) resident = 1;
@@ -473,6 +378,26 @@ static int bf_chunks(int nq, int64_t nd, int resident, int qpl, int group, long 
     return (int)std::max<long long>(1, (nd + rpc - 1) / rpc);
 }
 
+// Scan + per-chunk merge into d_packed, partials in `partial` (room for chunkLimit * nq words).
+static int bf_scan_into(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t* d_packed, unsigned long long* partial,
+                        int chunks, long long rpc, hipStream_t st) {
+    const int qBlocks = (nq + 256 * BF_QPL - 1) / (256 * BF_QPL);
+    if (bf->n > 0) {
+        hipLaunchKernelGGL(k_bf_scan, dim3(qBlocks, chunks), dim3(256), 0, st, (const uint32_t*)d_q, nq,
+                           (const uint32_t*)bf->d_db, (long long)bf->n, rpc, (long long)bf->globalBase, partial);
+    } else {
+        HIP_TRY(hipMemsetAsync(partial, 0xFF, (size_t)nq * 8, st));
+    }
+    hipLaunchKernelGGL(k_bf_merge, dim3((nq + 255) / 256), dim3(256), 0, st, (const unsigned long long*)partial, chunks,
+                       nq, (unsigned long long*)d_packed, (int32_t*)nullptr, (uint16_t*)nullptr, (uint16_t*)nullptr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        orb_set_error("brute-force launch failed: %s", hipGetErrorString(e));
+        return ORB_ERR_HIP;
+    }
+    return ORB_OK;
+}
+
 extern "C" int orb_bf_query_packed_device(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t* d_packed, void* stream) {
     if (!bf || nq < 0 || (nq > 0 && (!d_q || !d_packed))) {
         orb_set_error("orb_bf_query_packed_device: bad arguments");
@@ -480,41 +405,11 @@ extern "C" int orb_bf_query_packed_device(orb_bf* bf, const uint8_t* d_q, int nq
     }
     if (nq == 0) return ORB_OK;
     HIP_TRY(hipSetDevice(bf->device));
-    hipStream_t st = (hipStream_t)stream;
-    if (bf->variant < 0) {
-        // ORBHIP_BF_VARIANT selects a tuning variant of the scan kernel by name (development aid)
-        bf->variant = BF_DEFAULT_VARIANT;
-        const char* env = getenv("ORBHIP_BF_VARIANT");
-        if (env)
-            for (size_t i = 0; i < sizeof(kBfVariants) / sizeof(kBfVariants[0]); i++)
-                if (!strcmp(env, kBfVariants[i].name)) bf->variant = (int)i;
-        int perCu = 0, cus = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kBfVariants[bf->variant].fn, 256, 0));
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, bf->device));
-        bf->residentBlocks = std::max(1, perCu) * std::max(1, cus);
-    }
-    const BfVariant& V = kBfVariants[bf->variant];
-    long long rpc = V.group;
-    const int chunks = bf_chunks(nq, bf->n, bf->residentBlocks, V.qpl, V.group, &rpc);
+    long long rpc = BF_GROUP;
+    const int chunks = bf_chunks(nq, bf->n, bf->residentBlocks, BF_QPL, BF_GROUP, 4096, &rpc);
     int rc = bf_ensure(bf->d_partial, bf->partialBytes, (size_t)chunks * nq * 8);
     if (rc) return rc;
-    const int qBlocks = (nq + 256 * V.qpl - 1) / (256 * V.qpl);
-    if (bf->n > 0) {
-        hipLaunchKernelGGL(V.fn, dim3(qBlocks, chunks), dim3(256), 0, st, (const uint32_t*)d_q, nq,
-                           (const uint32_t*)bf->d_db, (long long)bf->n, rpc, (long long)bf->globalBase,
-                           (unsigned long long*)bf->d_partial);
-    } else {
-        HIP_TRY(hipMemsetAsync(bf->d_partial, 0xFF, (size_t)nq * 8, st));
-    }
-    hipLaunchKernelGGL(k_bf_merge, dim3((nq + 255) / 256), dim3(256), 0, st, (const unsigned long long*)bf->d_partial,
-                       chunks, nq, (unsigned long long*)d_packed, (int32_t*)nullptr, (uint16_t*)nullptr,
-                       (uint16_t*)nullptr);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) {
-        orb_set_error("brute-force launch failed: %s", hipGetErrorString(e));
-        return ORB_ERR_HIP;
-    }
-    return ORB_OK;
+    return bf_scan_into(bf, d_q, nq, d_packed, (unsigned long long*)bf->d_partial, chunks, rpc, (hipStream_t)stream);
 }
 
 extern "C" int orb_bf_merge_packed_device(int device, const uint64_t* d_gathered, int nshards, int nq,
