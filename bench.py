@@ -24,9 +24,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, spec
-# 32-bit integer VALU ops (v_xor_b32, v_bcnt_u32_b32) retire 16 lanes per clock and SIMD on gfx950
-# (tools/valu_peak.hip measures 37.7-38.1 T lane-ops/s for either alone): 256 CUs x 4 SIMDs x 16 x 2.4 GHz.
-VALU_LANE_OPS = 256 * 4 * 16 * 2.4e9
+# Ceiling of the Hamming loop (8 x v_xor_b32 + 8 x accumulating v_bcnt_u32_b32 per comparison), measured with
+# tools/valu_peak.hip on this chip (profiles/r02_valu_peak_8waves_per_simd.txt): v_bcnt_u32_b32 is a single-rate
+# instruction (16 lanes per clock and SIMD: 38 T lane-ops/s over 1024 SIMDs at 2.4 GHz), v_xor_b32 with two
+# VGPR sources a double-rate one (28-29 lanes per clock: 70 T), so a pair costs 6 cycles per wavefront at
+# best = 21.3 lanes per clock = 52.4 T lane-ops/s; the best order of the bare pair the micro-benchmark found
+# sustains 49.4 T (20.1 lanes per clock).  That measured figure is the peak the scan kernel is priced against.
+VALU_LANE_OPS = 49.4e12
+VALU_LANE_OPS_SINGLE_RATE = 256 * 4 * 16 * 2.4e9   # what both instructions would give at 16 lanes per clock
 
 
 def level_geometry(w, h, nlevels, scale):
@@ -247,9 +252,12 @@ def main():
             "metric": "Hamming matches Gcmp/s (brute-force top-2)", "value": round(gcmp, 2), "unit": "Gcmp/s",
             "queries": nq, "db_rows": nd, "rows_per_rank": hi - lo, "steps": args.bf_steps, "scaling": "strong",
             "ms_per_step": round(dth / args.bf_steps * 1e3, 3),
-            "roofline": {"bound": "valu", "kernel": "k_bf_top2", "achieved": round(lane_ops / 1e12, 3),
+            "roofline": {"bound": "valu", "kernel": "k_bf_top2_lds", "achieved": round(lane_ops / 1e12, 3),
                          "peak": round(VALU_LANE_OPS / 1e12, 3), "unit": "T lane-ops/s",
-                         "frac": round(lane_ops / VALU_LANE_OPS, 4), "launch_ms": round(kms, 3),
+                         "frac": round(lane_ops / VALU_LANE_OPS, 4),
+                         "peak_source": "tools/valu_peak.hip: best sustained v_xor_b32 + v_bcnt_u32_b32 pair rate (profiles/r02_valu_peak_8waves_per_simd.txt)",
+                         "frac_of_single_rate_peak": round(lane_ops / VALU_LANE_OPS_SINGLE_RATE, 4),
+                         "launch_ms": round(kms, 3),
                          "db_stream_GBs": round((hi - lo) * 32 * ((nq + 255) // 256) / (kms * 1e-3) / 1e9, 1)},
         }
         if rank == 0 and not args.no_cpu and world == 1:

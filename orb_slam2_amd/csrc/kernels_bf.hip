@@ -46,14 +46,6 @@ struct orb_bf {
     int residentBlocks = 0;  // workgroups of the scan kernel the device holds at once
 };
 
-// popcount(x) + acc in one instruction; written as asm because the compiler
-// otherwise splits the chain into bcnt(x, 0) plus separate three-operand adds.
-static __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
-    uint32_t r;
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
-    return r;
-}
-
 struct Row256 {  // one database row, the same for every lane of the wavefront
     uint4 lo, hi;
 };
@@ -65,15 +57,51 @@ static __device__ __forceinline__ Row256 load_row(const uint32_t* __restrict__ p
     return r;
 }
 
+// popcount of the 256-bit XOR of a query (a) and a row (r): 8 x (v_xor_b32 + accumulating v_bcnt_u32_b32).
+// One asm statement, for two reasons.  The compiler otherwise splits the accumulation into bcnt(x, 0) plus
+// separate adds.  And the scalar no-op between a v_xor and the v_bcnt that reads its result matters: v_xor_b32
+// is a double-rate instruction on gfx950 (a wavefront's 64 lanes in about 2 cycles), v_bcnt_u32_b32 a
+// single-rate one (4 cycles), yet a wavefront that issues the v_bcnt straight after the v_xor costs the SIMD
+// about 7.8 cycles per pair, whatever the distance between the two; with one scalar instruction after the
+// v_xor the pair takes about 6.6, and a further one after the v_bcnt makes it 8.3 (tools/valu_peak.hip measures
+// these orders).  Between separate asm statements the compiler adds such a no-op of its own, hence one statement.
+// PATTERN selects the order (a tuning parameter; the product uses BF_PATTERN): 0 = no scalar instruction,
+// 1 = s_nop 0 after every v_xor, 2 = s_nop 1 after every v_xor, 3 = every v_xor issued one pair ahead of
+// the v_bcnt that reads it, s_nop 0 between.
+#define BF_X(k, K) "v_xor_b32 %1, %" #k ", %" #K "\n\t"
+#define BF_X2(k, K) "v_xor_b32 %2, %" #k ", %" #K "\n\t"
+#define BF_B0 "v_bcnt_u32_b32 %0, %1, 0\n\t"
+#define BF_B "v_bcnt_u32_b32 %0, %1, %0\n\t"
+#define BF_B2 "v_bcnt_u32_b32 %0, %2, %0\n\t"
+#define BF_N0 "s_nop 0\n\t"
+#define BF_N1 "s_nop 1\n\t"
+#define BF_INS(a, r)                                                                                                  \
+    "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(r.lo.x), "v"(r.lo.y), \
+        "v"(r.lo.z), "v"(r.lo.w), "v"(r.hi.x), "v"(r.hi.y), "v"(r.hi.z), "v"(r.hi.w)
+template <int PATTERN>
 static __device__ __forceinline__ uint32_t hamming256(const uint32_t (&a)[8], const Row256& r) {
-    uint32_t d = __builtin_popcount(a[0] ^ r.lo.x);
-    d = bcnt_acc(a[1] ^ r.lo.y, d);
-    d = bcnt_acc(a[2] ^ r.lo.z, d);
-    d = bcnt_acc(a[3] ^ r.lo.w, d);
-    d = bcnt_acc(a[4] ^ r.hi.x, d);
-    d = bcnt_acc(a[5] ^ r.hi.y, d);
-    d = bcnt_acc(a[6] ^ r.hi.z, d);
-    d = bcnt_acc(a[7] ^ r.hi.w, d);
+    uint32_t d, t, u;
+    if (PATTERN == 0) {
+        asm(BF_X(3, 11) BF_B0 BF_X(4, 12) BF_B BF_X(5, 13) BF_B BF_X(6, 14) BF_B BF_X(7, 15) BF_B BF_X(8, 16) BF_B BF_X(9, 17)
+                BF_B BF_X(10, 18) BF_B
+            : "=&v"(d), "=&v"(t), "=&v"(u)
+            : BF_INS(a, r));
+    } else if (PATTERN == 1) {
+        asm(BF_X(3, 11) BF_N0 BF_B0 BF_X(4, 12) BF_N0 BF_B BF_X(5, 13) BF_N0 BF_B BF_X(6, 14) BF_N0 BF_B BF_X(7, 15) BF_N0 BF_B
+                BF_X(8, 16) BF_N0 BF_B BF_X(9, 17) BF_N0 BF_B BF_X(10, 18) BF_N0 BF_B
+            : "=&v"(d), "=&v"(t), "=&v"(u)
+            : BF_INS(a, r));
+    } else if (PATTERN == 2) {
+        asm(BF_X(3, 11) BF_N1 BF_B0 BF_X(4, 12) BF_N1 BF_B BF_X(5, 13) BF_N1 BF_B BF_X(6, 14) BF_N1 BF_B BF_X(7, 15) BF_N1 BF_B
+                BF_X(8, 16) BF_N1 BF_B BF_X(9, 17) BF_N1 BF_B BF_X(10, 18) BF_N1 BF_B
+            : "=&v"(d), "=&v"(t), "=&v"(u)
+            : BF_INS(a, r));
+    } else {
+        asm(BF_X(3, 11) BF_X2(4, 12) BF_N0 BF_B0 BF_X(5, 13) BF_N0 BF_B2 BF_X2(6, 14) BF_N0 BF_B BF_X(7, 15) BF_N0 BF_B2
+                BF_X2(8, 16) BF_N0 BF_B BF_X(9, 17) BF_N0 BF_B2 BF_X2(10, 18) BF_N0 BF_B BF_N0 BF_B2
+            : "=&v"(d), "=&v"(t), "=&v"(u)
+            : BF_INS(a, r));
+    }
     return d;
 }
 
@@ -91,7 +119,7 @@ static __device__ __forceinline__ void top2_update(uint32_t d, uint32_t row, uin
 }
 
 // One group of GROUP rows against the lane's QPL queries.
-template <int QPL, int GROUP>
+template <int QPL, int GROUP, int PATTERN>
 static __device__ __forceinline__ void bf_group(const uint32_t (&qv)[QPL][8], const Row256 (&rw)[GROUP], uint32_t rowBase,
                                                 uint32_t (&bd)[QPL], uint32_t (&bi)[QPL], uint32_t (&sd)[QPL]) {
     uint32_t d[GROUP][QPL];
@@ -100,7 +128,7 @@ static __device__ __forceinline__ void bf_group(const uint32_t (&qv)[QPL][8], co
     for (int g = 0; g < GROUP; g++) {
 #pragma unroll
         for (int j = 0; j < QPL; j++) {
-            d[g][j] = hamming256(qv[j], rw[g]);
+            d[g][j] = hamming256<PATTERN>(qv[j], rw[g]);
         }
     }
     // one compare per query against the smallest distance of the group
@@ -120,7 +148,7 @@ static __device__ __forceinline__ void bf_group(const uint32_t (&qv)[QPL][8], co
     }
 }
 
-template <int QPL, int GROUP, int TR>
+template <int QPL, int GROUP, int TR, int PATTERN>
 __global__ __launch_bounds__(256) void k_bf_top2_lds(const uint32_t* __restrict__ q, int nq,
                                                      const uint32_t* __restrict__ db, long long nd,
                                                      long long rowsPerChunk, long long globalBase,
@@ -180,13 +208,13 @@ __global__ __launch_bounds__(256) void k_bf_top2_lds(const uint32_t* __restrict_
                 Row256 rw[GROUP];
 #pragma unroll
                 for (int g = 0; g < GROUP; g++) rw[g] = load_row(tile + (r + g) * 8);
-                bf_group<QPL, GROUP>(qv, rw, (uint32_t)(t - r0) + r, bd, bi, sd);
+                bf_group<QPL, GROUP, PATTERN>(qv, rw, (uint32_t)(t - r0) + r, bd, bi, sd);
             }
             for (; r < rowsHere; r++) {
                 const Row256 row = load_row(tile + r * 8);
 #pragma unroll
                 for (int j = 0; j < QPL; j++)
-                    top2_update(hamming256(qv[j], row), (uint32_t)(t - r0) + r, bd[j], bi[j], sd[j]);
+                    top2_update(hamming256<PATTERN>(qv[j], row), (uint32_t)(t - r0) + r, bd[j], bi[j], sd[j]);
             }
         }
         if (more) stash(buf ^ 1);
@@ -210,8 +238,9 @@ __global__ __launch_bounds__(256) void k_bf_top2_lds(const uint32_t* __restrict_
 #define BF_QPL 2
 #define BF_GROUP 4
 #define BF_TILE_ROWS 128
+#define BF_PATTERN 1
 typedef void (*bf_kernel_t)(const uint32_t*, int, const uint32_t*, long long, long long, long long, unsigned long long*);
-static const bf_kernel_t k_bf_scan = k_bf_top2_lds<BF_QPL, BF_GROUP, BF_TILE_ROWS>;
+static const bf_kernel_t k_bf_scan = k_bf_top2_lds<BF_QPL, BF_GROUP, BF_TILE_ROWS, BF_PATTERN>;
 
 // Combine nshards packed candidates per query.  Inserting every shard's best
 // (distance, row) and second distance into one running top-2 equals scanning

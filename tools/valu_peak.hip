@@ -147,6 +147,19 @@ __global__ __launch_bounds__(256) void k_fixed(const unsigned* __restrict__ in, 
             if (MODE == 5) asm volatile(BLK_PAIR_DIFF_BANK_PIPELINED ::: FIXED_CLOBBERS);
             if (MODE == 6) asm volatile(BLK_PAIR_DIFF_BANK_ONE_CHAIN ::: FIXED_CLOBBERS);
             if (MODE == 7) asm volatile(BLK_PAIR_SAME_BANK_ONE_CHAIN ::: FIXED_CLOBBERS);
+            if (MODE == 8) asm volatile(BLK_PAIR_NOP_BETWEEN ::: FIXED_CLOBBERS);
+            if (MODE == 9) asm volatile(BLK_PAIR_NOP_EVERYWHERE ::: FIXED_CLOBBERS);
+            if (MODE == 10) asm volatile(BLK_PAIR_SKEWED ::: FIXED_CLOBBERS);
+            if (MODE == 11) asm volatile(BLK_PAIR_SKEWED_NOP ::: FIXED_CLOBBERS);
+            if (MODE == 12) asm volatile(BLK_PAIR_2X2 ::: FIXED_CLOBBERS);
+            if (MODE == 13) asm volatile(BLK_BCNT_ONLY ::: FIXED_CLOBBERS);
+            if (MODE == 14) asm volatile(BLK_BCNT_NOP ::: FIXED_CLOBBERS);
+            if (MODE == 15) asm volatile(BLK_XOR_NOP ::: FIXED_CLOBBERS);
+            if (MODE == 16) asm volatile(BLK_PAIR_FILL_SADD ::: FIXED_CLOBBERS, "s20", "scc");
+            if (MODE == 17) asm volatile(BLK_PAIR_FILL_SMOV ::: FIXED_CLOBBERS, "s20", "scc");
+            if (MODE == 18) asm volatile(BLK_PAIR_FILL_SCMP ::: FIXED_CLOBBERS, "s20", "scc");
+            if (MODE == 19) asm volatile(BLK_PAIR_FILL_VNOP ::: FIXED_CLOBBERS, "s20", "scc");
+            if (MODE == 20) asm volatile(BLK_PAIR_FILL_SSLEEP ::: FIXED_CLOBBERS, "s20", "scc");
         }
     }
     const unsigned long long c1 = clock64(), w1 = wall_clock64();
@@ -228,5 +241,18 @@ int main(int argc, char** argv) {
     run<5, true>("fixed regs: 4 xor(two banks), then 4 bcnt", blk, in, out, blocks, d_clk, wallKHz);
     run<6, true>("fixed regs: xor(two banks) + bcnt, 1 chain", blk, in, out, blocks, d_clk, wallKHz);
     run<7, true>("fixed regs: xor(one bank) + bcnt, 1 chain", blk, in, out, blocks, d_clk, wallKHz);
+    run<8, true>("fixed regs: xor, s_nop, bcnt", blk, in, out, blocks, d_clk, wallKHz);
+    run<9, true>("fixed regs: xor, s_nop, bcnt, s_nop", blk, in, out, blocks, d_clk, wallKHz);
+    run<10, true>("fixed regs: xor, bcnt of the previous xor", blk, in, out, blocks, d_clk, wallKHz);
+    run<11, true>("fixed regs: xor, s_nop, bcnt of the previous xor", blk, in, out, blocks, d_clk, wallKHz);
+    run<12, true>("fixed regs: 2 xor, 2 bcnt", blk, in, out, blocks, d_clk, wallKHz);
+    run<13, true>("fixed regs: bcnt", blk, in, out, blocks, d_clk, wallKHz);
+    run<14, true>("fixed regs: bcnt, s_nop", blk, in, out, blocks, d_clk, wallKHz);
+    run<15, true>("fixed regs: xor, s_nop", blk, in, out, blocks, d_clk, wallKHz);
+    run<16, true>("fixed regs: xor, s_add_u32, bcnt", blk, in, out, blocks, d_clk, wallKHz);
+    run<17, true>("fixed regs: xor, s_mov_b32, bcnt", blk, in, out, blocks, d_clk, wallKHz);
+    run<18, true>("fixed regs: xor, s_cmp_lg_u32, bcnt", blk, in, out, blocks, d_clk, wallKHz);
+    run<19, true>("fixed regs: xor, v_nop, bcnt", blk, in, out, blocks, d_clk, wallKHz);
+    run<20, true>("fixed regs: xor, s_sleep 0, bcnt", blk, in, out, blocks, d_clk, wallKHz);
     return 0;
 }

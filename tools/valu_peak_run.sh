@@ -1,10 +1,7 @@
 #!/bin/bash
-# Runs the VALU rate micro-benchmark (tools/valu_peak, built beforehand) and samples the engine clock
-# rocm-smi reports while it runs.  usage: tools/valu_peak_run.sh <outdir>
+# Runs the VALU rate micro-benchmark (tools/valu_peak, built beforehand) with 8, 2 and 1 wavefronts per SIMD.
+# usage: tools/valu_peak_run.sh <outdir>
 OUT=$1; mkdir -p $OUT
-( for i in $(seq 1 12); do rocm-smi --showclocks 2>/dev/null | grep -i "sclk" >> $OUT/sclk_samples.txt; sleep 0.4; done ) &
-SMI=$!
-timeout -k 10 120 $GRAFT_REPO_ROOT/tools/valu_peak > $OUT/valu_peak.txt 2>&1
-rc=$?
-wait $SMI
-exit $rc
+timeout -k 10 120 $GRAFT_REPO_ROOT/tools/valu_peak 2048 > $OUT/valu_peak_8waves.txt 2>&1 &&
+timeout -k 10 120 $GRAFT_REPO_ROOT/tools/valu_peak 512 > $OUT/valu_peak_2waves.txt 2>&1 &&
+timeout -k 10 120 $GRAFT_REPO_ROOT/tools/valu_peak 256 > $OUT/valu_peak_1wave.txt 2>&1
