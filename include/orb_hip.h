@@ -274,6 +274,18 @@ int orb_bf_query_top2(orb_bf* bf, const uint8_t* q, int nq, int32_t* best_idx, u
  * (0xFFFF / 0xFFFFFFFF when the shard holds fewer than 1 / 2 rows). */
 int orb_bf_query_packed_device(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t* d_packed, void* stream);
 
+/* orb_bf_query_packed_device for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * it).  No counterpart in the reference.  Same arguments and result, but the
+ * per-chunk partial results live in a fixed 32 MiB block inside the library's
+ * device image instead of a buffer grown on demand, and the call makes no
+ * hipMalloc / hipFree.  At most ORB_BF_NOALLOC_MAX_QUERIES queries per call
+ * (more: ORB_ERR_CAPACITY, nothing is launched).  All calls on one device share
+ * the block: calls that overlap in time on the same device race, whichever
+ * handles or streams they use. */
+#define ORB_BF_NOALLOC_MAX_QUERIES 262144
+int orb_bf_query_packed_noalloc(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t* d_packed, void* stream);
+
 /* Merge nshards packed results per query (d_gathered[s*nq + i], the layout an
  * all-gather produces) into the final answer; equals a scan of the whole
  * database.  Device buffers, asynchronous. */

@@ -17,6 +17,7 @@ ORB_Q_RESIZE_AREA, ORB_Q_UMAX_FORK, ORB_Q_DIVIDE_N3, ORB_Q_GRID_EXCLUSIVE, ORB_Q
     1 << i for i in range(6)
 )
 ORB_QUIRKS_FORK = 0x1F
+ORB_BF_NOALLOC_MAX_QUERIES = 262144  # include/orb_hip.h
 ORB_QUIRKS_CANONICAL = 0
 
 KP_DTYPE = np.dtype(
@@ -28,7 +29,7 @@ EXPORTS = [
     "orb_extract_batch_device", "orb_check_last_batch", "orb_get_pyramid_level", "orb_get_tables",
     "orb_debug_get_fast_keys", "orb_resize", "orb_gaussian_blur", "orb_hamming", "orb_match_window",
     "orb_match_window_batch_device", "orb_match_projected", "orb_bf_create", "orb_bf_destroy", "orb_bf_set_database",
-    "orb_bf_set_database_device", "orb_bf_query_top2", "orb_bf_query_packed_device", "orb_bf_merge_packed_device",
+    "orb_bf_set_database_device", "orb_bf_query_top2", "orb_bf_query_packed_device", "orb_bf_query_packed_noalloc", "orb_bf_merge_packed_device",
     "orb_enable_stage_timing", "orb_get_stage_timings", "orb_last_error", "orb_version",
     "orb_distinctive_descriptors", "orb_distinctive_descriptors_device",
     "orb_undistort_keypoints", "orb_undistort_keypoints_device", "orb_compute_image_bounds", "orb_set_image_bounds",
@@ -415,6 +416,10 @@ class BruteForce:
 
     def query_packed_device(self, d_q, d_packed, stream=None):
         _check(lib().orb_bf_query_packed_device(self.h, _dp(d_q), d_q.shape[0], _dp(d_packed), _stream(stream)))
+
+    def query_packed_noalloc(self, d_q, d_packed, stream=None):
+        """The same through the entry point that allocates nothing (fixed partials block in the library)."""
+        _check(lib().orb_bf_query_packed_noalloc(self.h, _dp(d_q), d_q.shape[0], _dp(d_packed), _stream(stream)))
 
 
 def merge_packed_device(device, d_gathered, nshards, nq, d_idx, d_best, d_second, stream=None):

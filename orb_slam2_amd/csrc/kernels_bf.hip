@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "orb_internal.h"
 
@@ -44,7 +45,37 @@ struct orb_bf {
     size_t outBytes = 0;
     hipStream_t stream = nullptr;
     int residentBlocks = 0;  // workgroups of the scan kernel the device holds at once
+    unsigned long long* d_static = nullptr;  // this device's copy of the library-held partials block (see below)
 };
+
+// Per-chunk partial results for orb_bf_query_packed_noalloc, the entry point for callers that must not
+// allocate: a fixed block in the library's device image instead of a buffer grown on demand.  Every device
+// the library is loaded on holds its own copy at its own address; host code never passes the array's
+// name to a kernel but the address hipGetSymbolAddress returned for that device (bf_static_block).
+// All calls on one device share the block, so calls that overlap in time on one device race.
+#define BF_STATIC_WORDS (4u << 20)  // 64-bit words: 32 MiB
+static __device__ __align__(256) unsigned long long g_bfStaticPartials[BF_STATIC_WORDS];
+
+#define BF_MAX_DEVICES 64
+static unsigned long long* g_bfStaticAddr[BF_MAX_DEVICES];
+static std::mutex g_bfStaticMutex;
+
+// Address of g_bfStaticPartials on `device`, which must be the current device.
+static int bf_static_block(int device, unsigned long long** out) {
+    if (device < 0 || device >= BF_MAX_DEVICES) {
+        orb_set_error("device ordinal %d beyond the %d the library keeps a partials block for", device, BF_MAX_DEVICES);
+        return ORB_ERR_UNSUPPORTED;
+    }
+    std::lock_guard<std::mutex> lock(g_bfStaticMutex);
+    if (!g_bfStaticAddr[device]) {
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_bfStaticPartials)));
+        g_bfStaticAddr[device] = (unsigned long long*)p;
+    }
+    *out = g_bfStaticAddr[device];
+    return ORB_OK;
+}
+
 
 struct Row256 {  // one database row, the same for every lane of the wavefront
     uint4 lo, hi;
@@ -287,6 +318,9 @@ extern "C" int orb_bf_create(int device, orb_bf** out) {
     HIP_TRY(hipSetDevice(device));
     // everything a query needs besides buffers is settled here, so that the query entry points make no
     // runtime call other than launches (and, for the growing variants, hipMalloc)
+    unsigned long long* block = nullptr;
+    int rc = bf_static_block(device, &block);
+    if (rc) return rc;
     int perCu = 0, cus = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_bf_scan, 256, 0));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
@@ -295,6 +329,7 @@ extern "C" int orb_bf_create(int device, orb_bf** out) {
     orb_bf* bf = new orb_bf();
     bf->device = device;
     bf->stream = st;
+    bf->d_static = block;
     bf->residentBlocks = std::max(1, perCu) * std::max(1, cus);
     *out = bf;
     return ORB_OK;
@@ -439,6 +474,25 @@ extern "C" int orb_bf_query_packed_device(orb_bf* bf, const uint8_t* d_q, int nq
     int rc = bf_ensure(bf->d_partial, bf->partialBytes, (size_t)chunks * nq * 8);
     if (rc) return rc;
     return bf_scan_into(bf, d_q, nq, d_packed, (unsigned long long*)bf->d_partial, chunks, rpc, (hipStream_t)stream);
+}
+
+extern "C" int orb_bf_query_packed_noalloc(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t* d_packed, void* stream) {
+    if (!bf || nq < 0 || (nq > 0 && (!d_q || !d_packed))) {
+        orb_set_error("orb_bf_query_packed_noalloc: bad arguments");
+        return ORB_ERR_INVALID;
+    }
+    if (nq > ORB_BF_NOALLOC_MAX_QUERIES) {
+        orb_set_error("orb_bf_query_packed_noalloc: %d queries exceed the limit of %d per call (split the query set, or use "
+                      "orb_bf_query_packed_device, which allocates)", nq, ORB_BF_NOALLOC_MAX_QUERIES);
+        return ORB_ERR_CAPACITY;
+    }
+    if (nq == 0) return ORB_OK;
+    HIP_TRY(hipSetDevice(bf->device));
+    // as many chunks as the fixed block has room for: ORB_BF_NOALLOC_MAX_QUERIES queries still get 16
+    long long rpc = BF_GROUP;
+    const int chunks = bf_chunks(nq, bf->n, bf->residentBlocks, BF_QPL, BF_GROUP, (long long)(BF_STATIC_WORDS / (unsigned)nq), &rpc);
+    // every (chunk, query) word is written by the scan before the merge reads it: nothing to clear between calls
+    return bf_scan_into(bf, d_q, nq, d_packed, bf->d_static, chunks, rpc, (hipStream_t)stream);
 }
 
 extern "C" int orb_bf_merge_packed_device(int device, const uint64_t* d_gathered, int nshards, int nq,
