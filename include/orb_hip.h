@@ -98,8 +98,9 @@ int orb_extract_batch_device(orb_ctx* ctx, const uint8_t* d_imgs, int n, int w, 
                              int64_t frame_stride, orb_keypoint* d_kps, uint8_t* d_desc, int cap_per_frame,
                              int* d_n_out, void* stream);
 
-/* After a *_device call has completed: 0 if no internal capacity or depth
- * limit was hit by the last batch, else ORB_ERR_CAPACITY (synchronises). */
+/* After *_device calls have completed: 0 if no internal capacity or depth
+ * limit was hit by the extraction batches and windowed-matcher calls since the
+ * last check, else ORB_ERR_CAPACITY (synchronises). */
 int orb_check_last_batch(orb_ctx* ctx);
 
 /* ORBextractor::mvImagePyramid[level] (include/ORBextractor.h:71) of frame
@@ -171,6 +172,21 @@ int orb_match_window_batch_device(orb_ctx* ctx, int npairs, const orb_keypoint* 
                                   const int* d_n2, int stride2, int img_w, int img_h, float* d_prev_xy,
                                   int* d_matches12, int window, float nnratio, int check_ori, int* d_nmatches,
                                   void* stream);
+
+/* Device memory of the windowed matchers (orb_match_window*, orb_match_projected,
+ * orb_match_local_map), grown on demand and kept by the context: per pair the
+ * searched frame's bucket-sorted grid (13 bytes per keypoint + 12 KB), per
+ * query 13 bytes of bookkeeping and a candidate list of min(stride2, 256)
+ * entries of 4 bytes (e.g. 64 pairs of 2070-keypoint frames: 136 MB), and one
+ * candidate pool for what windows hold beyond their first 256 candidates: 4 Mi
+ * entries (16 MiB) to start with, never more than the worst case.  A call whose
+ * windows overrun the pool fails with ORB_ERR_CAPACITY (the asynchronous entry
+ * point through orb_check_last_batch), nothing is truncated, and the pool is
+ * grown to what that call needed before the next one; the host-pointer entry
+ * points grow it and run again by themselves.  orb_match_reserve_candidates sets
+ * the pool size (entries) ahead of time, e.g. before asynchronous calls with
+ * whole-image windows: the worst case is pairs * stride1 * (stride2 - 256). */
+int orb_match_reserve_candidates(orb_ctx* ctx, long long entries);
 
 /* Kernel-level form of ORBmatcher::SearchByProjection(Frame&, const Frame&,
  * th, bMono), src/ORBmatcher.cc:279-408: the caller projects the last frame's

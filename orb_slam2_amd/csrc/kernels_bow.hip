@@ -476,11 +476,11 @@ __global__ __launch_bounds__(256) void k_bow_match(const BowSegment* __restrict_
 // Rotation consistency (src/ORBmatcher.cc:242-265) and the match count.  One workgroup.
 __global__ __launch_bounds__(256) void k_bow_finish(int nF, int checkOri, int* __restrict__ matchKF,
                                                     const int* __restrict__ binOf, int* __restrict__ nmatches) {
-    __shared__ int histo[ORB_HISTO];
+    __shared__ int histo[ORB_HISTO + 1];  // entry ORB_HISTO: rotations rot_bin could not place
     __shared__ int keep[3];
     __shared__ int count;
     const int t = threadIdx.x;
-    if (t < ORB_HISTO) histo[t] = 0;
+    if (t <= ORB_HISTO) histo[t] = 0;
     if (t == 0) count = 0;
     __syncthreads();
     if (checkOri) {

@@ -75,6 +75,10 @@ static __device__ __forceinline__ Window window_cells(float x, float y, float r,
 }
 
 
+#define M_LIST_SEG 256   // list entries every query owns (the resolve kernel stages the first 128 without a test)
+#define M_ERR_LIMIT 1    // error word bits: keypoint counts beyond the kernels' limits
+#define M_ERR_POOL 2     // the candidate pool ran out; the second error word holds the entries the call needed
+
 // Device scratch of one call, per pair: the sorted grid of the searched frame and the per-query
 // candidate lists.
 struct MatchBuffers {
@@ -82,12 +86,22 @@ struct MatchBuffers {
     float2* gXY;         // [npairs][stride2]  keypoint position by sorted position
     uint8_t* gOct;       // [npairs][stride2]  keypoint octave by sorted position
     int* cellStart;      // [npairs][M_CELLS + 1]
-    uint32_t* lists;     // [npairs][stride1][capQ]  distance << 16 | sorted position
+    uint32_t* lists;     // [npairs][stride1][capQ]  distance << 16 | sorted position: a query's first capQ candidates
     int* counts;         // [npairs][stride1]
     int* accepted;       // [npairs][stride1]  keypoint a query was matched to when it was resolved, -1 otherwise
     int* order;          // [npairs][stride1]  queries with a non-empty list, ascending
-    int capQ;
+    int capQ;            // min(stride2, M_LIST_SEG)
+    uint32_t* pool;      // [poolCap] candidates beyond a query's first capQ, handed out by an atomic counter
+    int* ovfStart;       // [npairs][stride1]  where in the pool a query's candidate number capQ sits
+    unsigned poolCap;
+    unsigned* poolUsed;  // entries asked for so far in this call (may exceed poolCap: then M_ERR_POOL is set)
 };
+
+// A query's candidate list: its first capQ entries in a fixed segment, the rest (wide windows over dense
+// frames) in the shared pool.
+static __device__ __forceinline__ uint32_t list_entry(const MatchBuffers& B, const uint32_t* seg, int ovf, int c) {
+    return c < B.capQ ? seg[c] : B.pool[(unsigned)ovf + (unsigned)(c - B.capQ)];
+}
 
 // Kernel 1.  Bucket assignment as the Frame constructor does it (PosInGrid): rounded position,
 // keypoints that fall outside the grid are left out.
@@ -106,7 +120,7 @@ __global__ __launch_bounds__(256) void k_grid_build(const orb_keypoint* __restri
     int* cellStart = B.cellStart + (int64_t)pair * (M_CELLS + 1);
     const int n2 = n2s ? n2s[pair] : n2const;
     if (n2 > stride2 || n2 > M_MAXKP || n2 < 0) {
-        if (t == 0) atomicOr(error, 1);
+        if (t == 0) atomicOr(error, M_ERR_LIMIT);
         for (int c = t; c <= M_CELLS; c += 256) cellStart[c] = 0;  // an empty grid: the later kernels find nothing
         return;
     }
@@ -215,7 +229,7 @@ __global__ __launch_bounds__(256) void k_match_lists(const orb_keypoint* __restr
                                                      const float* __restrict__ v, const float* __restrict__ radius,
                                                      const int* __restrict__ minLevel, const int* __restrict__ maxLevel,
                                                      const uint8_t* __restrict__ d2all, int stride2, GridGeom G,
-                                                     unsigned quirks, MatchBuffers B) {
+                                                     unsigned quirks, MatchBuffers B, int* __restrict__ error) {
     const int pair = blockIdx.y, lane = threadIdx.x & 63;
     const int q = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // uniform per wavefront
     const int nq = PROJECTED ? nqConst : n1s[pair];
@@ -259,35 +273,57 @@ __global__ __launch_bounds__(256) void k_match_lists(const orb_keypoint* __restr
     const uint4 a0 = ((const uint4*)qd)[0], a1 = ((const uint4*)qd)[1];
     const bool checkLevels = lmin >= 0 || lmax >= 0;
     const float r2 = __fmul_rn(r, r);
-    int n = 0;
-    for (int base = lo; base < hi; base += 64) {
-        const int p = base + lane;
-        bool ok = false;
-        uint32_t key = 0;
-        if (p < hi) {
-            key = gS[p];
-            const int iy = (int)(key >> 16) % ORB_GRID_ROWS;
-            ok = iy >= w.y0 && iy < w.y1;
-            if (ok && checkLevels) {
-                const int o = gO[p];
-                if (o < lmin) ok = false;
-                if (lmax >= 0 && o > lmax) ok = false;
+    // pass 0 fills the query's segment; a query with more than capQ candidates (rare) then takes room for the
+    // rest from the pool and walks its window once more for them
+    int n = 0, ovf = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        n = 0;
+        for (int base = lo; base < hi; base += 64) {
+            const int p = base + lane;
+            bool ok = false;
+            uint32_t key = 0;
+            if (p < hi) {
+                key = gS[p];
+                const int iy = (int)(key >> 16) % ORB_GRID_ROWS;
+                ok = iy >= w.y0 && iy < w.y1;
+                if (ok && checkLevels) {
+                    const int o = gO[p];
+                    if (o < lmin) ok = false;
+                    if (lmax >= 0 && o > lmax) ok = false;
+                }
+                if (ok) {
+                    const float2 c = gXY[p];
+                    const float dx = __fsub_rn(c.x, x), dy = __fsub_rn(c.y, y);
+                    ok = circ ? (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < r2) : (fabsf(dx) < r && fabsf(dy) < r);
+                }
             }
+            const unsigned long long b = __ballot(ok);
             if (ok) {
-                const float2 c = gXY[p];
-                const float dx = __fsub_rn(c.x, x), dy = __fsub_rn(c.y, y);
-                ok = circ ? (__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) < r2) : (fabsf(dx) < r && fabsf(dy) < r);
+                const int pos = n + __popcll(b & ((1ull << lane) - 1ull));
+                if (pass == 0 ? pos < B.capQ : pos >= B.capQ) {
+                    const uint32_t dist = (uint32_t)hamming_rows(a0, a1, d2 + (int64_t)(key & 0xFFFFu) * 32);
+                    if (pass == 0) list[pos] = (dist << 16) | (uint32_t)p;
+                    else B.pool[(unsigned)ovf + (unsigned)(pos - B.capQ)] = (dist << 16) | (uint32_t)p;
+                }
             }
+            n += __popcll(b);
         }
-        const unsigned long long b = __ballot(ok);
-        if (ok) {
-            const uint32_t dist = (uint32_t)hamming_rows(a0, a1, d2 + (int64_t)(key & 0xFFFFu) * 32);
-            const int pos = n + __popcll(b & ((1ull << lane) - 1ull));
-            if (pos < B.capQ) list[pos] = (dist << 16) | (uint32_t)p;
+        if (pass == 1 || n <= B.capQ) break;
+        unsigned start = 0;
+        if (lane == 0) start = atomicAdd(B.poolUsed, (unsigned)(n - B.capQ));
+        start = __shfl(start, 0, 64);
+        if (start + (unsigned)(n - B.capQ) > B.poolCap || start + (unsigned)(n - B.capQ) < start) {
+            // nothing is truncated silently: the call reports ORB_ERR_CAPACITY and what it would have needed
+            if (lane == 0) atomicOr(error, M_ERR_POOL);
+            n = B.capQ;
+            break;
         }
-        n += __popcll(b);
+        ovf = (int)start;
     }
-    if (lane == 0) counts[q] = n < B.capQ ? n : B.capQ;  // n <= keypoints in the grid <= capQ
+    if (lane == 0) {
+        counts[q] = n;
+        B.ovfStart[(int64_t)pair * stride1 + q] = ovf;
+    }
 }
 
 // Best candidate of every query on its own, for the searches in which one query's outcome does not
@@ -360,7 +396,7 @@ struct ResolveLds {
     // the keypoint's octave in bits 8-15 for the projected ones.  High half: owner (vnMatches21 / the
     // query whose map point the keypoint holds).
     uint32_t so[M_MAXKP];
-    int hist[ORB_HISTO];
+    int hist[ORB_HISTO + 1];  // entry ORB_HISTO: rotations rot_bin could not place
     int wcount[4];
     int nmatches;
 };
@@ -393,7 +429,7 @@ __global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __res
     const int n2 = n2s ? n2s[pair] : n2const;
     if (nq > stride1 || nq > 32767 || n2 > stride2 || n2 > M_MAXKP) {
         if (t == 0) {
-            atomicOr(error, 1);
+            atomicOr(error, M_ERR_LIMIT);
             nmatchesOut[pair] = 0;
         }
         return;
@@ -414,7 +450,7 @@ __global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __res
                       (occupied2 && occupied2[i2] ? 1u : 0u);
         else S.so[p] = 0xFFFFFFFFu;                                            // distance INT_MAX, owner -1
     }
-    if (t < ORB_HISTO) S.hist[t] = 0;
+    if (t <= ORB_HISTO) S.hist[t] = 0;
     if (t == 0) S.nmatches = 0;
     __syncthreads();
 
@@ -504,7 +540,11 @@ __global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __res
                 };
                 if (lane < cnt) consider(e0);
                 if (lane + 64 < cnt) consider(e1);
-                for (int c = lane + 128; c < cnt; c += 64) consider(lists[(int64_t)i1 * B.capQ + c]);
+                if (cnt > 128) {
+                    const uint32_t* seg = lists + (int64_t)i1 * B.capQ;
+                    const int ovf = B.ovfStart[(int64_t)pair * stride1 + i1];
+                    for (int c = lane + 128; c < cnt; c += 64) consider(list_entry(B, seg, ovf, c));
+                }
                 if (MODE == 1) k1 = wave_min_u32(k1);
                 else wave_top2_u32(k1, k2);
                 e0 = n0;
@@ -618,7 +658,10 @@ struct MatchState {
     // scratch, grown on demand and kept
     void* gSorted = nullptr; void* gXY = nullptr; void* gOct = nullptr; void* cellStart = nullptr;
     void* lists = nullptr; void* counts = nullptr; void* accepted = nullptr; void* order = nullptr;
-    void* binOf = nullptr;
+    void* binOf = nullptr; void* ovfStart = nullptr;
+    void* pool = nullptr;   // shared candidate pool (see MatchBuffers)
+    size_t poolCap = 0;     // entries
+    size_t poolWanted = 0;  // entries the next call should have (set when a call ran out, or by orb_match_reserve_candidates)
     size_t capPairs2 = 0;   // npairs * stride2 the grid arrays hold
     size_t capPairs = 0;    // pairs cellStart holds
     size_t capPairs1 = 0;   // npairs * stride1 the per-query arrays hold
@@ -631,7 +674,8 @@ struct MatchState {
 void orb_match_state_free(void* p) {
     MatchState* s = (MatchState*)p;
     if (!s) return;
-    void* bufs[] = {s->err, s->gSorted, s->gXY, s->gOct, s->cellStart, s->lists, s->counts, s->accepted, s->order, s->binOf};
+    void* bufs[] = {s->err, s->gSorted, s->gXY, s->gOct, s->cellStart, s->lists, s->counts, s->accepted, s->order, s->binOf,
+                    s->ovfStart, s->pool};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (s->blockDev) (void)hipFree(s->blockDev);
@@ -660,13 +704,15 @@ static int grow(void** p, size_t bytes) {
     return ORB_OK;
 }
 
+#define M_POOL_DEFAULT ((size_t)4 << 20)   // pool entries (16 MiB) a context starts with
+
 // Makes the scratch large enough for npairs pairs of (stride1 queries, stride2 searched keypoints).
 static int match_buffers(orb_ctx* c, int npairs, int stride1, int stride2, MatchState** out, MatchBuffers* B) {
     void** slot = orb_ctx_match_state(c);
     if (!*slot) {
         MatchState* s = new MatchState();
-        hipError_t e = hipMalloc(&s->err, 4);
-        if (e == hipSuccess) e = hipMemset(s->err, 0, 4);
+        hipError_t e = hipMalloc(&s->err, 8);  // flags, pool entries asked for
+        if (e == hipSuccess) e = hipMemset(s->err, 0, 8);
         if (e != hipSuccess) {
             delete s;
             orb_set_error("matcher state allocation failed: %s", hipGetErrorString(e));
@@ -677,8 +723,22 @@ static int match_buffers(orb_ctx* c, int npairs, int stride1, int stride2, Match
     MatchState* s = (MatchState*)*slot;
     int rc;
     const size_t p2 = (size_t)npairs * stride2, p1 = (size_t)npairs * stride1;
-    const int capQ = stride2;  // a window can hold every keypoint of the searched frame
+    // Every query owns min(stride2, M_LIST_SEG) list entries; what a wide window over a dense frame holds beyond
+    // that comes from a pool shared by the call's queries.  The worst case (every window holds every keypoint)
+    // would take p1 * stride2 entries - 8.8 GB for 512 pairs of 2000-feature frames; the pool starts at what
+    // the worst case needs or M_POOL_DEFAULT entries, whichever is smaller, and a call that runs out reports
+    // ORB_ERR_CAPACITY (host-pointer entry points grow the pool and run again instead).
+    const int capQ = stride2 < M_LIST_SEG ? stride2 : M_LIST_SEG;
     const size_t nl = p1 * (size_t)capQ;
+    const size_t worst = p1 * (size_t)(stride2 - capQ);
+    size_t poolNeed = worst < M_POOL_DEFAULT ? worst : M_POOL_DEFAULT;
+    if (s->poolWanted > poolNeed) poolNeed = s->poolWanted < worst ? s->poolWanted : worst;
+    if (poolNeed > 0xFFFFFFF0ull) poolNeed = 0xFFFFFFF0ull;
+    if (poolNeed > s->poolCap) {
+        s->poolCap = 0;
+        if ((rc = grow(&s->pool, poolNeed * 4))) return rc;
+        s->poolCap = poolNeed;
+    }
     if (p2 > s->capPairs2) {
         s->capPairs2 = 0;
         if ((rc = grow(&s->gSorted, p2 * 4))) return rc;
@@ -697,6 +757,7 @@ static int match_buffers(orb_ctx* c, int npairs, int stride1, int stride2, Match
         if ((rc = grow(&s->accepted, p1 * 4))) return rc;
         if ((rc = grow(&s->order, p1 * 4))) return rc;
         if ((rc = grow(&s->binOf, p1))) return rc;
+        if ((rc = grow(&s->ovfStart, p1 * 4))) return rc;
         s->capPairs1 = p1;
     }
     if (nl > s->capLists) {
@@ -713,6 +774,10 @@ static int match_buffers(orb_ctx* c, int npairs, int stride1, int stride2, Match
     B->accepted = (int*)s->accepted;
     B->order = (int*)s->order;
     B->capQ = capQ;
+    B->pool = (uint32_t*)s->pool;
+    B->ovfStart = (int*)s->ovfStart;
+    B->poolCap = (unsigned)s->poolCap;
+    B->poolUsed = (unsigned*)s->err + 1;
     *out = s;
     return ORB_OK;
 }
@@ -777,9 +842,11 @@ extern "C" int orb_match_window_batch_device(orb_ctx* c, int npairs, const orb_k
     hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(256), 0, st, d_k2, d_n2, 0, stride2, G, B,
                        (int*)s->err);
     if ((rc = check_match_launch())) return rc;
+    HIP_TRY(hipMemsetAsync(B.poolUsed, 0, 4, st));
     hipLaunchKernelGGL(k_match_lists<false>, dim3((stride1 + 3) / 4, npairs), dim3(256), 0, st, d_k1, d_d1, d_n1, 0,
                        stride1, (const float*)d_prev_xy, (float)window, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const int*)nullptr, (const int*)nullptr, d_d2, stride2, G, orb_ctx_quirks(c), B);
+                       (const float*)nullptr, (const int*)nullptr, (const int*)nullptr, d_d2, stride2, G, orb_ctx_quirks(c), B,
+                       (int*)s->err);
     if ((rc = check_match_launch())) return rc;
     hipLaunchKernelGGL(k_match_resolve<0>, dim3(npairs), dim3(256), 0, st, d_k1, d_n1, 0, stride1, d_k2, d_n2, 0,
                        stride2, d_prev_xy, d_matches12, (uint8_t*)s->binOf, (const float*)nullptr,
@@ -820,18 +887,53 @@ static int ensure_block(MatchState* s, size_t bytes) {
     return ORB_OK;
 }
 
-static int match_error(const int* flag, MatchState* s, const char* what) {
-    if (*flag) {
+// Error words of the last call as the host read them (flag[0] bits, flag[1] pool entries asked for).
+// M_RETRY: the candidate pool ran out and has been marked for growth; the caller runs the call again.
+#define M_RETRY 1
+static int match_error(const int* flag, MatchState* s, const char* what, bool mayRetry) {
+    if (flag[0]) {
         HIP_TRY(hipMemset(s->err, 0, 4));
-        orb_set_error("%s: keypoint count exceeds the kernel's limits", what);
+        if (flag[0] & M_ERR_LIMIT) {
+            orb_set_error("%s: keypoint count exceeds the kernel's limits", what);
+            return ORB_ERR_CAPACITY;
+        }
+        const size_t need = (size_t)(unsigned)flag[1];
+        s->poolWanted = need + need / 8;
+        if (mayRetry) return M_RETRY;
+        orb_set_error("%s: search windows hold more candidates than the context's candidate pool (%zu entries, %zu needed); "
+                      "the pool grows with the next call, or reserve it with orb_match_reserve_candidates", what, s->poolCap,
+                      need);
         return ORB_ERR_CAPACITY;
     }
     return ORB_OK;
 }
 
-extern "C" int orb_match_window(orb_ctx* c, const orb_keypoint* k1, const uint8_t* d1, int n1, const orb_keypoint* k2,
-                                const uint8_t* d2, int n2, int img_w, int img_h, float* prev_xy, int* matches12,
-                                int window, float nnratio, int check_ori, int* nmatches) {
+// For the asynchronous entry points: called by orb_check_last_batch once the device is idle.
+int orb_match_check_error(orb_ctx* c) {
+    MatchState* s = (MatchState*)*orb_ctx_match_state(c);
+    if (!s) return ORB_OK;
+    int flag[2] = {0, 0};
+    HIP_TRY(hipMemcpy(flag, s->err, 8, hipMemcpyDeviceToHost));
+    return match_error(flag, s, "windowed matcher", false);
+}
+
+extern "C" int orb_match_reserve_candidates(orb_ctx* c, long long entries) {
+    if (!c || entries < 0) {
+        orb_set_error("orb_match_reserve_candidates: bad arguments");
+        return ORB_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(orb_ctx_device(c)));
+    MatchState* s = nullptr;
+    MatchBuffers B;
+    int rc = match_buffers(c, 1, 1, 1, &s, &B);  // (creates the state on first use)
+    if (rc) return rc;
+    if ((size_t)entries > s->poolWanted) s->poolWanted = (size_t)entries;
+    return ORB_OK;
+}
+
+static int match_window_once(orb_ctx* c, const orb_keypoint* k1, const uint8_t* d1, int n1, const orb_keypoint* k2,
+                             const uint8_t* d2, int n2, int img_w, int img_h, float* prev_xy, int* matches12, int window,
+                             float nnratio, int check_ori, int* nmatches, bool mayRetry) {
     if (!c || n1 < 0 || n2 < 0 || !nmatches || (n1 > 0 && (!k1 || !d1 || !prev_xy || !matches12)) ||
         (n2 > 0 && (!k2 || !d2)) || img_w < 1 || img_h < 1) {
         orb_set_error("orb_match_window: bad arguments");
@@ -849,7 +951,7 @@ extern "C" int orb_match_window(orb_ctx* c, const orb_keypoint* k1, const uint8_
     const size_t oK1 = L.add((size_t)n1 * sizeof(orb_keypoint)), oD1 = L.add((size_t)n1 * 32);
     const size_t oK2 = L.add((size_t)s2 * sizeof(orb_keypoint)), oD2 = L.add((size_t)s2 * 32), oN = L.add(8);
     const size_t oPrev = L.add((size_t)n1 * 8);  // in and out
-    const size_t oM = L.add((size_t)n1 * 4), oNm = L.add(4), oErr = L.add(4);
+    const size_t oM = L.add((size_t)n1 * 4), oNm = L.add(4), oErr = L.add(8);
     if ((rc = ensure_block(s, L.off))) return rc;
     uint8_t* h = (uint8_t*)s->blockHost;
     uint8_t* d = (uint8_t*)s->blockDev;
@@ -868,22 +970,35 @@ extern "C" int orb_match_window(orb_ctx* c, const orb_keypoint* k1, const uint8_
                                        (float*)(d + oPrev), (int*)(d + oM), window, nnratio, check_ori, (int*)(d + oNm),
                                        nullptr);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(d + oErr, s->err, 4, hipMemcpyDeviceToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(d + oErr, s->err, 8, hipMemcpyDeviceToDevice, nullptr));
     HIP_TRY(hipMemcpyAsync(h + oPrev, d + oPrev, L.off - oPrev, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
-    if ((rc = match_error((const int*)(h + oErr), s, "windowed matcher"))) return rc;
+    if ((rc = match_error((const int*)(h + oErr), s, "windowed matcher", mayRetry))) return rc;
     memcpy(prev_xy, h + oPrev, (size_t)n1 * 8);
     memcpy(matches12, h + oM, (size_t)n1 * 4);
     memcpy(nmatches, h + oNm, 4);
     return ORB_OK;
 }
 
+extern "C" int orb_match_window(orb_ctx* c, const orb_keypoint* k1, const uint8_t* d1, int n1, const orb_keypoint* k2,
+                                const uint8_t* d2, int n2, int img_w, int img_h, float* prev_xy, int* matches12,
+                                int window, float nnratio, int check_ori, int* nmatches) {
+    // inputs are only read and outputs only written on success, so a call whose windows overran the candidate
+    // pool is simply made again once the pool has grown
+    int rc = match_window_once(c, k1, d1, n1, k2, d2, n2, img_w, img_h, prev_xy, matches12, window, nnratio, check_ori,
+                               nmatches, true);
+    if (rc == M_RETRY)
+        rc = match_window_once(c, k1, d1, n1, k2, d2, n2, img_w, img_h, prev_xy, matches12, window, nnratio, check_ori,
+                               nmatches, false);
+    return rc;
+}
+
 // mode 1: best candidate only, rotation check on request; mode 2: local-map rule (no rotation check).
-static int match_projected(orb_ctx* c, int mode, const float* u, const float* v, const float* radius,
-                           const int* min_level, const int* max_level, const float* qangle, const uint8_t* qdesc,
-                           const uint8_t* qobs, int nq, const orb_keypoint* k2, const uint8_t* d2, int n2, int img_w,
-                           int img_h, const uint8_t* occupied2, int* match2, int th_high, float nnratio, int check_ori,
-                           int* nmatches) {
+static int match_projected_once(orb_ctx* c, int mode, const float* u, const float* v, const float* radius,
+                                const int* min_level, const int* max_level, const float* qangle, const uint8_t* qdesc,
+                                const uint8_t* qobs, int nq, const orb_keypoint* k2, const uint8_t* d2, int n2, int img_w,
+                                int img_h, const uint8_t* occupied2, int* match2, int th_high, float nnratio,
+                                int check_ori, int* nmatches, bool mayRetry) {
     if (!c || nq < 0 || n2 < 0 || !nmatches || (n2 > 0 && (!k2 || !d2 || !match2)) ||
         (nq > 0 && (!u || !v || !radius || !min_level || !max_level || (check_ori && !qangle) || !qdesc)) || img_w < 1 ||
         img_h < 1) {
@@ -910,7 +1025,7 @@ static int match_projected(orb_ctx* c, int mode, const float* u, const float* v,
     const size_t oL0 = L.add((size_t)nq * 4), oL1 = L.add((size_t)nq * 4), oA = L.add((size_t)nq * 4);
     const size_t oQ = L.add((size_t)nq * 32), oObs = L.add((size_t)nq);
     const size_t oK2 = L.add((size_t)n2 * sizeof(orb_keypoint)), oD2 = L.add((size_t)n2 * 32), oOcc = L.add((size_t)n2);
-    const size_t oM = L.add((size_t)n2 * 4), oNm = L.add(4), oErr = L.add(4);  // outputs
+    const size_t oM = L.add((size_t)n2 * 4), oNm = L.add(4), oErr = L.add(8);  // outputs
     if ((rc = ensure_block(s, L.off))) return rc;
     uint8_t* h = (uint8_t*)s->blockHost;
     uint8_t* d = (uint8_t*)s->blockDev;
@@ -931,10 +1046,11 @@ static int match_projected(orb_ctx* c, int mode, const float* u, const float* v,
     hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, st, (const orb_keypoint*)(d + oK2), (const int*)nullptr, n2, n2,
                        G, B, (int*)s->err);
     if ((rc = check_match_launch())) return rc;
+    HIP_TRY(hipMemsetAsync(B.poolUsed, 0, 4, st));
     hipLaunchKernelGGL(k_match_lists<true>, dim3((nq + 3) / 4, 1), dim3(256), 0, st, (const orb_keypoint*)nullptr,
                        (const uint8_t*)(d + oQ), (const int*)nullptr, nq, nq, (const float*)nullptr, 0.f,
                        (const float*)(d + oU), (const float*)(d + oV), (const float*)(d + oR), (const int*)(d + oL0),
-                       (const int*)(d + oL1), (const uint8_t*)(d + oD2), n2, G, orb_ctx_quirks(c), B);
+                       (const int*)(d + oL1), (const uint8_t*)(d + oD2), n2, G, orb_ctx_quirks(c), B, (int*)s->err);
     if ((rc = check_match_launch())) return rc;
     hipLaunchKernelGGL(mode == 2 ? k_match_resolve<2> : k_match_resolve<1>, dim3(1), dim3(256), 0, st,
                        (const orb_keypoint*)nullptr, (const int*)nullptr, nq, nq, (const orb_keypoint*)(d + oK2),
@@ -943,13 +1059,26 @@ static int match_projected(orb_ctx* c, int mode, const float* u, const float* v,
                        occupied2 ? (const uint8_t*)(d + oOcc) : (const uint8_t*)nullptr, (int*)(d + oM), nnratio, th_high,
                        check_ori, B, (int*)(d + oNm), (int*)s->err);
     if ((rc = check_match_launch())) return rc;
-    HIP_TRY(hipMemcpyAsync(d + oErr, s->err, 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + oErr, s->err, 8, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(h + oM, d + oM, L.off - oM, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if ((rc = match_error((const int*)(h + oErr), s, "projected matcher"))) return rc;
+    if ((rc = match_error((const int*)(h + oErr), s, "projected matcher", mayRetry))) return rc;
     memcpy(match2, h + oM, (size_t)n2 * 4);
     memcpy(nmatches, h + oNm, 4);
     return ORB_OK;
+}
+
+static int match_projected(orb_ctx* c, int mode, const float* u, const float* v, const float* radius,
+                           const int* min_level, const int* max_level, const float* qangle, const uint8_t* qdesc,
+                           const uint8_t* qobs, int nq, const orb_keypoint* k2, const uint8_t* d2, int n2, int img_w,
+                           int img_h, const uint8_t* occupied2, int* match2, int th_high, float nnratio, int check_ori,
+                           int* nmatches) {
+    int rc = match_projected_once(c, mode, u, v, radius, min_level, max_level, qangle, qdesc, qobs, nq, k2, d2, n2, img_w,
+                                  img_h, occupied2, match2, th_high, nnratio, check_ori, nmatches, true);
+    if (rc == M_RETRY)
+        rc = match_projected_once(c, mode, u, v, radius, min_level, max_level, qangle, qdesc, qobs, nq, k2, d2, n2, img_w,
+                                  img_h, occupied2, match2, th_high, nnratio, check_ori, nmatches, false);
+    return rc;
 }
 
 extern "C" int orb_match_projected(orb_ctx* c, const float* u, const float* v, const float* radius,
@@ -1006,7 +1135,7 @@ extern "C" int orb_match_best(orb_ctx* c, const float* u, const float* v, const 
     const size_t oU = L.add((size_t)nq * 4), oV = L.add((size_t)nq * 4), oR = L.add((size_t)nq * 4);
     const size_t oL0 = L.add((size_t)nq * 4), oL1 = L.add((size_t)nq * 4), oQ = L.add((size_t)nq * 32);
     const size_t oK2 = L.add((size_t)n2 * sizeof(orb_keypoint)), oD2 = L.add((size_t)n2 * 32), oSig = L.add(256 * 4);
-    const size_t oIdx = L.add((size_t)nq * 4), oDist = L.add((size_t)nq * 4), oErr = L.add(4);  // outputs
+    const size_t oIdx = L.add((size_t)nq * 4), oDist = L.add((size_t)nq * 4), oErr = L.add(8);  // outputs
     if ((rc = ensure_block(s, L.off))) return rc;
     uint8_t* h = (uint8_t*)s->blockHost;
     uint8_t* d = (uint8_t*)s->blockDev;
@@ -1030,10 +1159,10 @@ extern "C" int orb_match_best(orb_ctx* c, const float* u, const float* v, const 
                        (const uint8_t*)(d + oD2), ns ? (const float*)(d + oSig) : (const float*)nullptr, ns, chi2_max, th, G,
                        orb_ctx_quirks(c), B, (int*)(d + oIdx), (int*)(d + oDist));
     if ((rc = check_match_launch())) return rc;
-    HIP_TRY(hipMemcpyAsync(d + oErr, s->err, 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + oErr, s->err, 8, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(h + oIdx, d + oIdx, L.off - oIdx, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if ((rc = match_error((const int*)(h + oErr), s, "orb_match_best"))) return rc;
+    if ((rc = match_error((const int*)(h + oErr), s, "orb_match_best", false))) return rc;
     memcpy(best_idx, h + oIdx, (size_t)nq * 4);
     if (best_dist) memcpy(best_dist, h + oDist, (size_t)nq * 4);
     return ORB_OK;

@@ -69,12 +69,17 @@ static __device__ __forceinline__ int hamming_rows(const uint4 a0, const uint4 a
            __builtin_popcount(a1.z ^ b1.z) + __builtin_popcount(a1.w ^ b1.w);
 }
 
+// Rotation histogram bin of a match, src/ORBmatcher.cc:94-102.  The reference asserts 0 <= bin < HISTO_LENGTH,
+// which holds for keypoint angles in [0, 360); for angles a caller made up outside that range the result here
+// is the extra bin ORB_HISTO, which the histograms hold as an entry three_maxima never looks at: such a match
+// counts for no orientation and is removed by the rotation check instead of indexing outside the histogram.
 static __device__ __forceinline__ int rot_bin(float a1, float a2) {
     const float factor = ORB_HISTO / 360.0f;  // src/ORBmatcher.cc:35
     float rot = __fsub_rn(a1, a2);
     if (rot < 0.0f) rot = __fadd_rn(rot, 360.0f);
     int bin = (int)roundf(__fmul_rn(rot, factor));
     if (bin == ORB_HISTO) bin = 0;
+    if (bin < 0 || bin > ORB_HISTO) bin = ORB_HISTO;
     return bin;
 }
 

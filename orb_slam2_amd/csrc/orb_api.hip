@@ -540,13 +540,24 @@ extern "C" int orb_create(const orb_params* prm, orb_ctx** out) {
     if (!c) return ORB_ERR_NOMEM;
     c->prm = *prm;
     build_tables(c);
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // a failing HIP call from here on must not leak the half-built context
+#define CREATE_TRY(call)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            orb_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            orb_destroy(c);                                                                           \
+            return ORB_ERR_HIP;                                                                       \
+        }                                                                                             \
+    } while (0)
+    CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i < ORB_MAX_PARTS - 1; i++) {
-        HIP_TRY(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&c->evJoin[i], hipEventDisableTiming));
+        CREATE_TRY(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
+        CREATE_TRY(hipEventCreateWithFlags(&c->evJoin[i], hipEventDisableTiming));
     }
-    HIP_TRY(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->evSeen, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&c->evSeen, hipEventDisableTiming));
+#undef CREATE_TRY
     {
         int rcPin = c->pinSeen.ensure(64);
         if (rcPin) {
@@ -733,6 +744,8 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
     return post_seen_keys(c, st);
 }
 
+int orb_match_check_error(orb_ctx* c);  // kernels_match.hip
+
 static int read_error_flag(orb_ctx* c) {
     int flag = 0;
     HIP_TRY(hipMemcpy(&flag, c->dError.p, 4, hipMemcpyDeviceToHost));
@@ -793,7 +806,9 @@ extern "C" int orb_check_last_batch(orb_ctx* c) {
     }
     HIP_TRY(hipSetDevice(c->prm.device));
     HIP_TRY(hipDeviceSynchronize());
-    return read_error_flag(c);
+    const int rc = read_error_flag(c);
+    const int rcMatch = orb_match_check_error(c);  // asynchronous matcher calls report through the same function
+    return rc ? rc : rcMatch;
 }
 
 extern "C" int orb_extract_batch_device(orb_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int stride,

@@ -328,6 +328,82 @@ def test_search_for_initialization(hip, oracle, preset):
     c.close()
 
 
+def _random_frame(hip, n, w, h, seed):
+    """n level-0 keypoints at random integer positions with random angles and descriptors."""
+    r = splitmix64(seed, n * 3)
+    k = np.zeros(n, hip.KP_DTYPE)
+    k["x"] = (r[:n] % np.uint64(w)).astype(np.float32)
+    k["y"] = (r[n : 2 * n] % np.uint64(h)).astype(np.float32)
+    k["angle"] = (r[2 * n :] % np.uint64(360)).astype(np.float32)
+    k["size"], k["octave"], k["class_id"] = 31, 0, -1
+    return k, synth_descriptors(n, seed + 1)
+
+
+def test_matcher_wide_windows_use_the_candidate_pool(hip, oracle):
+    """Windows that hold more candidates than a query's fixed list segment (256) put the rest into the shared
+    pool; a call that overruns the pool is made again with a larger one (host entry point) or reports
+    ORB_ERR_CAPACITY through orb_check_last_batch and succeeds once the pool has grown (asynchronous entry)."""
+    import torch
+
+    w, h = 752, 480
+    k2, d2 = _random_frame(hip, 4000, w, h, 31)
+    # (queries, window): overflow within the initial pool; then 3000 x ~3700 entries, beyond its 4 Mi
+    for n1, window in ((300, 150), (700, 2000), (3000, 2000)):
+        c = _ctx(hip, "fork", 2000, 8, w, h)
+        k1, d1 = _random_frame(hip, n1, w, h, 77 + n1)
+        m = len(d1[::3])  # a third of the queries have a near-duplicate close by, at the same orientation
+        d1[::3] = d2[:m] ^ np.uint8(1)
+        k1["angle"][::3] = k2["angle"][:m]
+        k1["x"][::3] = np.clip(k2["x"][:m] + 3, 0, w - 1)
+        k1["y"][::3] = np.clip(k2["y"][:m] - 2, 0, h - 1)
+        prev = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32)
+        ng, mg, pg = c.match_window(k1, d1, k2, d2, w, h, prev, window, 0.9, True)
+        no, mo, po = oracle.search_for_initialization(k1, d1, k2, d2, w, h, prev, window, 0.9, True, PRESETS["fork"])
+        assert ng == no and no > n1 // 6
+        np.testing.assert_array_equal(mg, mo)
+        np.testing.assert_array_equal(pg, po)
+        if n1 == 3000:
+            # asynchronous entry point on a fresh context: the first call overruns the pool and says so ...
+            c2 = _ctx(hip, "fork", 2000, 8, w, h)
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            d_k1, d_d1, d_k2, d_d2 = t(k1.view(np.uint8).reshape(1, n1, 28)), t(d1[None]), t(k2.view(np.uint8).reshape(1, 4000, 28)), t(d2[None])
+            d_n1, d_n2 = t(np.array([n1], np.int32)), t(np.array([4000], np.int32))
+            d_m12 = torch.zeros((1, n1), dtype=torch.int32, device="cuda")
+            d_nm = torch.zeros(1, dtype=torch.int32, device="cuda")
+            d_prev = t(prev[None])
+            c2.match_window_batch_device(d_k1, d_d1, d_n1, d_k2, d_d2, d_n2, w, h, d_prev, d_m12, d_nm, window, 0.9, True)
+            with pytest.raises(hip.OrbError, match="candidate pool"):
+                c2.check_last_batch()
+            # ... the next one runs with the pool that call asked for
+            d_prev = t(prev[None])
+            c2.match_window_batch_device(d_k1, d_d1, d_n1, d_k2, d_d2, d_n2, w, h, d_prev, d_m12, d_nm, window, 0.9, True)
+            c2.check_last_batch()
+            assert int(d_nm.item()) == no
+            np.testing.assert_array_equal(d_m12[0].cpu().numpy(), mo)
+            c2.close()
+        c.close()
+
+
+def test_out_of_range_angles_do_not_leave_the_histogram(hip, oracle):
+    """The reference asserts that a rotation bin lies in [0, 30), which keypoint angles in [0, 360) guarantee.
+    Angles a caller made up outside that range land in an extra bin no maximum can pick: those matches are
+    removed by the rotation check, every other query keeps a valid result."""
+    w, h = 752, 480
+    c = _ctx(hip, "fork", 2000, 8, w, h)
+    k1, d1, k2, d2 = _pair(oracle, w, h, 2000, frame_seed(3, 7), "fork")
+    prev = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32)
+    n_ok, m_ok, _ = c.match_window(k1, d1, k2, d2, w, h, prev, 100, 0.9, True)
+    bad = np.flatnonzero(m_ok >= 0)[::5]
+    k1b = k1.copy()
+    k1b["angle"][bad[0::3]] = 1.0e4
+    k1b["angle"][bad[1::3]] = -1.0e4
+    k1b["angle"][bad[2::3]] = 3.0e9
+    n, m, _ = c.match_window(k1b, d1, k2, d2, w, h, prev, 100, 0.9, True)
+    assert (m[bad] == -1).all() and ((m >= -1) & (m < len(k2))).all()
+    assert n == int((m >= 0).sum()) and 0 < n < n_ok
+    c.close()
+
+
 @pytest.mark.parametrize("preset", ["fork", "canonical"])
 def test_search_by_projection(hip, oracle, preset):
     w, h = 640, 480
