@@ -4,13 +4,20 @@
 One process per GPU (launched by torch.distributed.run for --gpus > 1).  A
 "step" is one pass of ORBextractor::operator() over a batch of synthetic
 640x480 frames that already sit in HBM (1000 features, 8 levels, scale 1.2 —
-the configuration the headline metric is quoted on).  Frames are independent,
+the configuration the headline metric is quoted on); consecutive steps take
+different batches (three of them, 470 MB together, more than the 256 MB
+Infinity Cache holds), so no step re-reads what the previous one left in
+cache.  Frames are independent,
 so ranks share nothing on the data path (weak scaling: every rank extracts its
 own batch).  The same JSON line also carries the brute-force Hamming workload
 (100k queries x 10M database rows, rows sharded over the ranks, packed top-2
 all-gathered over RCCL and merged), the roofline of the dominant extraction
-kernel from HIP-event stage timings, and the CPU oracle timed on a bounded
-sample of the same frames.
+kernel from HIP-event stage timings, the CPU oracle timed on a bounded
+sample of the same frames, and - so that one line tells the whole story, not
+only the most favourable operating point - the same extraction at other batch
+sizes, through the host-pointer entry points (PCIe-inclusive), one frame at a
+time, and the other benchmark configurations (KITTI-shaped, EuRoC-shaped
+pairs with matching, 4K), all timed in this run.  None of those enter `value`.
 """
 import argparse
 import json
@@ -62,6 +69,7 @@ def main():
     ap.add_argument("--no-hamming", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=100)
+    ap.add_argument("--no-extras", action="store_true", help="skip batch sweep, host path, single frame and other configurations")
     args = ap.parse_args()
 
     import torch
@@ -112,16 +120,21 @@ def main():
 
     # ---- extraction ---------------------------------------------------------------------
     frames = np.stack([synth_scene(W, H, frame_seed(1, rank * B + f)) for f in range(B)])
-    d_imgs = torch.from_numpy(frames).to(dev)
+    d_base = torch.from_numpy(frames).to(dev)
+    # three distinct batches: the drawn frames, mirrored left-right, mirrored top-bottom (other corners, other
+    # keypoints; made on the device so that the run does not spend a minute drawing scenes)
+    d_batches = [d_base, torch.flip(d_base, dims=[2]).contiguous(), torch.flip(d_base, dims=[1]).contiguous()]
     ctx = binding.Context(args.nfeatures, 1.2, 8, 20, 7, W, H, B, local, quirks)
     cap = ctx.cap
     d_kps = torch.zeros((B, cap, 28), dtype=torch.uint8, device=dev)
     d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
     d_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream()
+    nstep = [0]
 
     def step():
-        ctx.extract_batch_device(d_imgs, d_kps, d_desc, d_cnt, stream)
+        ctx.extract_batch_device(d_batches[nstep[0] % 3], d_kps, d_desc, d_cnt, stream)
+        nstep[0] += 1
 
     note("context created")
     for _ in range(args.warmup):
@@ -149,6 +162,9 @@ def main():
     stage_ms, nrec = ctx.stage_timings()
     ctx.enable_stage_timing(False)
     ctx.check_last_batch()
+    nstep[0] = 0
+    step()  # leave the results of the drawn frames in the output buffers for the parity check below
+    torch.cuda.synchronize()
     counts = d_cnt.cpu().numpy()
     fps = world * B * args.steps / dt
 
@@ -167,8 +183,11 @@ def main():
     achieved = stage_bytes[dom] * B / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms[dom] > 0 else 0.0
     # HBM-side bytes and VALU instruction counts of the same kernel from the committed rocprofv3 --pmc passes
     # (tools/pmc_collect.sh; counters are per launch at the batch size recorded in the file, scaled to this batch).
-    traffic, valu = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_per_kernel.json")
+    traffic, valu, pmc_source = None, None, None
+    import glob
+
+    tables = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_kernel.json")))
+    pmc_path = tables[-1] if tables else ""
     if os.path.exists(pmc_path) and dom != "pyramid" and args.width == 640 and args.height == 480 and args.nfeatures == 1000:
         with open(pmc_path) as fh:
             table = json.load(fh)
@@ -176,18 +195,23 @@ def main():
         if pk:
             k = B / pk["batch"]
             cn = pk["counters_per_launch"]
+            pmc_source = os.path.relpath(pmc_path, ROOT)
             if "FETCH_SIZE" in cn and "WRITE_SIZE" in cn:
                 # counter unit KB; gfx950 tallies a 128-byte read request as 64 bytes (tools/fetch_calib.hip
                 # reads 512 MiB with 4- and 16-byte loads per lane: FETCH_SIZE reports 256 MiB, WRITE_SIZE is exact)
                 traffic = int((2 * cn["FETCH_SIZE"] + cn["WRITE_SIZE"]) * 1024 * k)
             if "SQ_INSTS_VALU" in cn:
                 wi = cn["SQ_INSTS_VALU"] * k
-                # one wave-instruction holds a SIMD's 16-lane ALU for 4 cycles; 1024 SIMDs at 2.4 GHz
+                # a single-rate wave-instruction holds a SIMD's ALU for 4 cycles (double-rate ones, such as a
+                # two-register v_add / v_xor / v_fma_f32, for 2: "util" prices every instruction at 4 and is an
+                # upper bound of the issue time); 1024 SIMDs at 2.4 GHz
                 valu = {"wave_instructions_per_launch": int(wi), "issue_cycles_per_instruction": 4,
                         "util": round(wi * 4 / (1024 * 2.4e9 * stage_ms[dom] * 1e-3), 4)}
     roofline = {
         "bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "valu_issue": valu,
+        "traffic_source": ("%s (rocprofv3 --pmc passes of an earlier run of this command, scaled to this batch; not "
+                           "collected in this run)" % pmc_source) if pmc_source else None,
         "algorithmic_bytes_per_launch": int(stage_bytes[dom] * B), "launch_ms": round(stage_ms[dom], 4),
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}, "stage_batches": nrec,
         "stage_timing": "HIP events between the stages, same steps repeated after the timed loop with group overlap off",
@@ -204,42 +228,31 @@ def main():
         gq = torch.Generator(device=dev)
         gq.manual_seed(99)
         d_q = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device=dev, generator=gq)
-        bf = binding.BruteForce(local)
-        bf.set_database_device(d_db, lo)
-        d_packed = torch.zeros(nq, dtype=torch.int64, device=dev)
-        d_gath = torch.zeros((world, nq), dtype=torch.int64, device=dev)
-        d_idx = torch.zeros(nq, dtype=torch.int32, device=dev)
-        d_b = torch.zeros(nq, dtype=torch.int16, device=dev)
-        d_s = torch.zeros(nq, dtype=torch.int16, device=dev)
+        # the class the multi-rank tests exercise (orb_slam2_amd/sharded.py): scan of this rank's rows, one
+        # all-gather of the packed words, merge on every rank; the scan is bracketed by events for the roofline
+        from orb_slam2_amd.sharded import ShardedBruteForce, hip_backend
+
+        scan, merge, bf = hip_backend(d_db, lo, local)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         kern_ms = []
+        last = {}
 
-        def bf_step(timed=False):
-            if timed:
-                ev0.record(stream)
-            bf.query_packed_device(d_q, d_packed, stream)
-            if timed:
-                ev1.record(stream)
-            if world > 1 and rehearse:  # gloo: through host memory
-                torch.cuda.synchronize()
-                h_gath = torch.zeros((world, nq), dtype=torch.int64)
-                dist.all_gather_into_tensor(h_gath.view(-1), d_packed.cpu())
-                d_gath.copy_(h_gath)
-                binding.merge_packed_device(local, d_gath, world, nq, d_idx, d_b, d_s, stream)
-            elif world > 1:
-                dist.all_gather_into_tensor(d_gath.view(-1), d_packed)
-                binding.merge_packed_device(local, d_gath, world, nq, d_idx, d_b, d_s, stream)
-            else:
-                binding.merge_packed_device(local, d_packed, 1, nq, d_idx, d_b, d_s, stream)
+        def timed_scan(q):
+            ev0.record(stream)
+            out = scan(q)
+            ev1.record(stream)
+            last["packed"] = out
+            return out
 
+        sbf = ShardedBruteForce(timed_scan, merge)
         note("database ready")
-        bf_step()
+        sbf.query(d_q)
         torch.cuda.synchronize()
         note("first brute-force step done")
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.bf_steps):
-            bf_step(timed=True)
+            d_idx, d_b, d_s = sbf.query(d_q)
             torch.cuda.synchronize()
             kern_ms.append(ev0.elapsed_time(ev1))
         barrier()
@@ -258,24 +271,53 @@ def main():
                          "peak_source": "tools/valu_peak.hip: best sustained v_xor_b32 + v_bcnt_u32_b32 pair rate (profiles/r02_valu_peak_8waves_per_simd.txt)",
                          "frac_of_single_rate_peak": round(lane_ops / VALU_LANE_OPS_SINGLE_RATE, 4),
                          "launch_ms": round(kms, 3),
-                         "db_stream_GBs": round((hi - lo) * 32 * ((nq + 255) // 256) / (kms * 1e-3) / 1e9, 1)},
+                         "db_stream_GBs": round((hi - lo) * 32 * ((nq + 511) // 512) / (kms * 1e-3) / 1e9, 1)},
         }
-        if rank == 0 and not args.no_cpu and world == 1:
+        if rank == 0 and not args.no_cpu:
+            import threading
+
             import oracle
 
-            sq, sd = 64, 500000
+            # CPU baseline: the scalar port on one thread over a bounded sample of the same data
+            sq, sd = 64, min(500000, hi - lo)
             qh = d_q[:sq].cpu().numpy()
             dbh = d_db[:sd].cpu().numpy()
             t0 = time.perf_counter()
-            io, bo, so = oracle.bf_top2(qh, dbh)
+            oracle.bf_top2(qh, dbh)
             tc = time.perf_counter() - t0
             hamming["cpu_baseline"] = {"value": round(sq * sd / tc / 1e9, 3), "unit": "Gcmp/s", "cores": 1, "kind": "port",
                                        "sample": "%d queries x %d rows, 4x popcount64 per pair" % (sq, sd)}
-            # same slice on the GPU must agree
-            bchk = binding.BruteForce(local)
-            bchk.set_database(dbh)
-            ig, bg, sg = bchk.query_top2(qh)
-            hamming["parity_checked"] = bool((ig == io).all() and (bg == bo).all() and (sg == so).all())
+            # parity of the TIMED result: a slice of its queries against the oracle's scan of the same rows
+            # (this rank's shard for the packed words; at one GPU that is the whole database and the final answer)
+            sel = np.arange(0, nq, max(1, nq // 192))[:192]
+            qs = d_q[torch.from_numpy(sel).to(dev)].cpu().numpy()
+            dball = d_db.cpu().numpy()
+            nthr = max(1, min(16, os.cpu_count() or 1))
+            parts = np.array_split(np.arange(len(sel)), nthr)
+            res = [None] * nthr
+
+            def work(k):
+                res[k] = oracle.bf_top2(qs[parts[k]], dball)
+
+            th = [threading.Thread(target=work, args=(k,)) for k in range(nthr)]
+            t0 = time.perf_counter()
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            tall = time.perf_counter() - t0
+            io, bo, so = (np.concatenate([r[k] for r in res]) for k in range(3))
+            pk = last["packed"].cpu().numpy().view(np.uint64)[sel]
+            ok = ((pk & np.uint64(0xFFFFFFFF)).astype(np.int64) == io.astype(np.int64) + lo).all() and \
+                 ((pk >> np.uint64(48)).astype(np.uint16) == bo).all() and \
+                 (((pk >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.uint16) == so).all()
+            if world == 1:
+                ok = ok and (d_idx.cpu().numpy()[sel] == io).all() and (d_b.cpu().numpy().view(np.uint16)[sel] == bo).all() \
+                     and (d_s.cpu().numpy().view(np.uint16)[sel] == so).all()
+            hamming["parity_checked"] = bool(ok)
+            hamming["parity_sample"] = "%d queries of the timed scan x all %d rows of rank 0 against the oracle" % (len(sel), hi - lo)
+            hamming["cpu_baseline"]["all_cores"] = {"value": round(len(sel) * (hi - lo) / tall / 1e9, 3), "unit": "Gcmp/s",
+                                                    "cores": nthr, "sample": "the parity sample, one slice per thread"}
 
     # ---- CPU baseline + parity spot check (rank 0, single GPU runs only) ----------------
     cpu = None
@@ -320,16 +362,97 @@ def main():
             cpu["all_cores"] = {"value": round(nthr * per / tm, 3), "unit": "frames/s", "cores": nthr,
                                 "sample": "%d frames per thread, one extractor per thread" % per}
 
+    # ---- the same extraction off the headline operating point, and the other configurations -----------
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = {}
+
+        def wall(fn, steps, warm=2):
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps
+
+        sweep = {}
+        for nb, steps in ((1, 200), (8, 100), (64, 50)):
+            if nb > B:
+                continue
+            k = [0]
+
+            def sub():
+                ctx.extract_batch_device(d_batches[k[0] % 3][(k[0] * nb) % (B - nb + 1):][:nb], d_kps[:nb], d_desc[:nb], d_cnt[:nb], stream)
+                k[0] += 1
+
+            t = wall(sub, steps)
+            sweep[str(nb)] = {"frames_per_s": round(nb / t, 1), "ms_per_batch": round(t * 1e3, 4)}
+        sweep[str(B)] = {"frames_per_s": round(fps, 1), "ms_per_batch": round(dt / args.steps * 1e3, 4)}
+        extras["batch_sweep"] = {"what": "device-resident frames, batches enqueued back to back, one synchronisation at the end",
+                                 "by_batch": sweep}
+        ctx.check_last_batch()
+        # host-pointer entry points: frames start and results end in pageable host memory (PCIe-inclusive)
+        nb = min(64, B)
+        host_imgs = [frames[f] for f in range(nb)]
+        t = wall(lambda: ctx.extract_batch(host_imgs), 10)
+        extras["host_path"] = {"entry_point": "orb_extract_batch (ctypes wrapper, which also allocates the result arrays)",
+                               "batch": nb, "frames_per_s": round(nb / t, 1), "ms_per_batch": round(t * 1e3, 3)}
+        one = [0]
+
+        def single():
+            ctx.extract(frames[one[0] % min(B, 16)])
+            one[0] += 1
+
+        t = wall(single, 200, warm=5)
+        single_ms = {"orb_extract_ctypes": round(t * 1e3, 4)}
+        demo = os.path.join(ROOT, "examples", "orb_demo")
+        if os.path.exists(demo):  # the drop-in C++ ORBextractor::operator() and Frame constructor, timed by the demo itself
+            import subprocess
+            import tempfile
+
+            with tempfile.TemporaryDirectory() as td:
+                fin = os.path.join(td, "in.bin")
+                with open(fin, "wb") as fh:
+                    fh.write(np.array([W, H, args.nfeatures, 100], np.int32).tobytes())
+                    fh.write(np.array([0.9], np.float32).tobytes())
+                    fh.write(frames[0].tobytes())
+                    fh.write(frames[1 % B].tobytes())
+                try:
+                    r = subprocess.run([demo, "--time", fin, "300"], capture_output=True, text=True, timeout=120)
+                    if r.returncode == 0:
+                        single_ms.update(json.loads(r.stdout.strip().splitlines()[-1]))
+                    else:
+                        single_ms["orb_demo_error"] = (r.stderr or r.stdout)[-200:]
+                except Exception as ex:  # the demo is an extra, never a reason to lose the benchmark line
+                    single_ms["orb_demo_error"] = str(ex)[-200:]
+        extras["single_frame_ms"] = single_ms
+        # the other configurations make contexts of their own; this one's streams would compete with theirs for the
+        # process's few hardware queues
+        ctx.close()
+        if not args.no_hamming:
+            bf.close()
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_configs
+
+            extras["other_configs"] = [bench_configs.config2(), bench_configs.config3(), bench_configs.config4()]
+        except Exception as ex:
+            extras["other_configs"] = {"error": str(ex)[-300:]}
+
     if rank == 0:
         out = {
             "metric": "ORB extract frames/s (640x480, 1k feats)", "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "ORBextractor::operator() over %d frames %dx%d per GPU per step, nFeatures=%d, 8 levels, scale 1.2, iniThFAST 20, minThFAST 7, preset %s"
+            "config": {"workload": "ORBextractor::operator() over %d frames %dx%d per GPU per step (three distinct batches in turn, inputs and outputs resident in HBM), nFeatures=%d, 8 levels, scale 1.2, iniThFAST 20, minThFAST 7, preset %s"
                                    % (B, W, H, args.nfeatures, args.preset),
                        "batch_per_gpu": B, "keypoints_per_frame": round(nkp, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "parity_checked": parity, "hamming": hamming,
         }
+        if extras:
+            out.update(extras)
         if rehearse:
             out["rehearsal"] = "ranks share GPUs, gloo collectives: not a measurement"
         print(json.dumps(out))

@@ -4,14 +4,18 @@
 // tests/test_gpu_cpp_dropin.py compares with the CPU oracle.
 //
 // usage: orb_demo <in.bin> <out.bin>
+//        orb_demo --time <in.bin> [repetitions]   wall time of ORBextractor::operator() and of the Frame
+//                                                 constructor on frame A, printed as one JSON object
 //   in.bin : int32 w, h, nfeatures, window; float nnratio; then 2 * w*h bytes (frame A, frame B)
 //   environment ORBDEMO_CAMERA="fx,fy,cx,cy,k1,k2,p1,p2,k3" replaces the default pinhole camera
 //   (fx = fy = 500, principal point at the image centre, no distortion)
 //   environment ORBDEMO_VOC=<vocabulary text file> adds Frame::ComputeBoW on both frames, the L1 score of
 //   their bag-of-words vectors and ORBmatcher::SearchByBoW with frame A in the keyframe's place
 //   environment ORBDEMO_LOCALMAP=1 adds ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "../orb_slam2_amd/cpp/Frame.h"
@@ -23,9 +27,14 @@ using namespace ORB_SLAM2;
 template <typename T>
 static void put(FILE* f, const T* p, size_t n) { fwrite(p, sizeof(T), n, f); }
 
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 int main(int argc, char** argv) {
     if (argc < 3) return 2;
-    FILE* fi = fopen(argv[1], "rb");
+    const bool timing = !strcmp(argv[1], "--time");
+    FILE* fi = fopen(argv[timing ? 2 : 1], "rb");
     if (!fi) return 3;
     int hdr[4];
     float nnratio;
@@ -50,11 +59,32 @@ int main(int argc, char** argv) {
             dist = cv::Mat(c[8] != 0.f ? 5 : 4, 1, CV_32F);  // src/Tracking.cc:76-88: k3 only when non-zero
             for (int i = 0; i < dist.rows; i++) dist.at<float>(i) = c[4 + i];
         }
+        if (timing) {
+            const int reps = argc > 3 ? atoi(argv[3]) : 200;
+            std::vector<cv::KeyPoint> kps;
+            cv::Mat desc;
+            for (int i = 0; i < 10; i++) ext(i & 1 ? imB : imA, cv::Mat(), kps, desc);  // context, buffers, code objects
+            double t0 = now_ms();
+            for (int i = 0; i < reps; i++) ext(i & 1 ? imB : imA, cv::Mat(), kps, desc);
+            const double tOp = (now_ms() - t0) / reps;
+            ext.SetKeepPyramid(true);
+            t0 = now_ms();
+            for (int i = 0; i < reps; i++) ext(i & 1 ? imB : imA, cv::Mat(), kps, desc);
+            const double tOpPyr = (now_ms() - t0) / reps;
+            ext.SetKeepPyramid(false);
+            { Frame warm(imA, 0.0, &ext, nullptr, K, dist, 40.f, 35.f); }
+            t0 = now_ms();
+            for (int i = 0; i < reps; i++) Frame F(i & 1 ? imB : imA, (double)i, &ext, nullptr, K, dist, 40.f, 35.f);
+            const double tFrame = (now_ms() - t0) / reps;
+            printf("{\"cpp_operator_ms\": %.4f, \"cpp_operator_with_pyramid_download_ms\": %.4f, \"cpp_frame_constructor_ms\": %.4f, "
+                   "\"cpp_keypoints\": %d, \"cpp_repetitions\": %d}\n", tOp, tOpPyr, tFrame, (int)kps.size(), reps);
+            return 0;
+        }
         ORBVocabulary voc;
         const char* vocPath = getenv("ORBDEMO_VOC");
         if (vocPath && !voc.loadFromTextFile(vocPath)) return 8;
         Frame F1(imA, 0.0, &ext, vocPath ? &voc : nullptr, K, dist, 40.f, 35.f);
-        std::vector<cv::Mat> pyrA = ext.mvImagePyramid;
+        std::vector<cv::Mat> pyrA = ext.GetImagePyramid();  // (downloaded on request; the member is not filled per frame)
         for (cv::Mat& m : pyrA) m = m.clone();
         Frame F2(imB, 1.0, &ext, vocPath ? &voc : nullptr, K, dist, 40.f, 35.f);
 

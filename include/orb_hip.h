@@ -107,11 +107,22 @@ int orb_check_last_batch(orb_ctx* ctx);
  * `frame` of the last batch, copied to host memory (ROI pixels, no padding). */
 int orb_get_pyramid_level(orb_ctx* ctx, int frame, int level, uint8_t* dst, int dst_stride, int* w, int* h);
 
+/* All levels of that frame with one synchronisation: dst[l] receives level l
+ * (rows dst_stride[l] bytes apart; sizes from orb_get_pyramid_level with a NULL
+ * destination). */
+int orb_get_pyramid(orb_ctx* ctx, int frame, uint8_t* const* dst, const int* dst_stride);
+
 /* GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
  * GetInverseScaleSigmaSquares (include/ORBextractor.h:50-68), the per-level
  * quotas mnFeaturesPerLevel and the 16-entry umax table.  NULL = skip. */
 int orb_get_tables(const orb_ctx* ctx, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2, int* per_level,
                    int* umax);
+
+/* The same tables from the constructor arguments alone (nfeatures, scale_factor,
+ * nlevels, quirks of *params): host arithmetic of src/ORBextractor.cc:377-435,
+ * no device, no context. */
+int orb_compute_tables(const orb_params* params, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                       int* per_level, int* umax);
 
 /* Stage access for parity tests: keys handed to DistributeOctTree for
  * (frame, level) of the last batch, in the reference's order

@@ -26,7 +26,8 @@ KP_DTYPE = np.dtype(
 
 EXPORTS = [
     "orb_create", "orb_destroy", "orb_max_keypoints_per_frame", "orb_extract", "orb_extract_batch",
-    "orb_extract_batch_device", "orb_check_last_batch", "orb_get_pyramid_level", "orb_get_tables",
+    "orb_extract_batch_device", "orb_check_last_batch", "orb_get_pyramid_level", "orb_get_pyramid", "orb_get_tables",
+    "orb_compute_tables",
     "orb_debug_get_fast_keys", "orb_resize", "orb_gaussian_blur", "orb_hamming", "orb_match_window",
     "orb_match_window_batch_device", "orb_match_reserve_candidates", "orb_match_projected", "orb_bf_create", "orb_bf_destroy", "orb_bf_set_database",
     "orb_bf_set_database_device", "orb_bf_query_top2", "orb_bf_query_packed_device", "orb_bf_query_packed_noalloc", "orb_bf_merge_packed_device",

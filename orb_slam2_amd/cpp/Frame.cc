@@ -100,7 +100,31 @@ void Frame::ExtractORB(int flag, const cv::Mat& im) {
         (*mpORBextractorRight)(im, cv::Mat(), mvKeysRight, mDescriptorsRight);
 }
 
-void Frame::SetPose(cv::Mat Tcw) { mTcw = Tcw.clone(); }
+void Frame::SetPose(cv::Mat Tcw) {
+    mTcw = Tcw.clone();
+    UpdatePoseMatrices();
+}
+
+// src/Frame.cc:146-166: mRcw = R, mRwc = R^T, mtcw = t, mOw = -R^T t of the 4x4 float pose.
+void Frame::UpdatePoseMatrices() {
+    if (mTcw.empty()) return;
+    mRcw.create(3, 3, CV_32F);
+    mRwc.create(3, 3, CV_32F);
+    mtcw.create(3, 1, CV_32F);
+    mOw.create(3, 1, CV_32F);
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) {
+            mRcw.at<float>(r, c) = mTcw.at<float>(r, c);
+            mRwc.at<float>(c, r) = mTcw.at<float>(r, c);
+        }
+        mtcw.at<float>(r, 0) = mTcw.at<float>(r, 3);
+    }
+    for (int r = 0; r < 3; r++) {
+        float s = 0.f;
+        for (int k = 0; k < 3; k++) s += mRwc.at<float>(r, k) * mtcw.at<float>(k, 0);
+        mOw.at<float>(r, 0) = -s;
+    }
+}
 
 // Camera matrix and distortion coefficients in the plain form the C ABI takes.  mDistCoef holds
 // k1, k2, p1, p2 and, when non-zero, k3 (src/Tracking.cc:76-88).

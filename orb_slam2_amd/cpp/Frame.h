@@ -1,8 +1,10 @@
 // Drop-in for the part of include/Frame.h of the reference that the ORB front
 // end touches: the monocular constructor, ExtractORB, the 64x48 bucket grid
 // with GetFeaturesInArea, ComputeBoW, and the public members ORBmatcher reads.
-// Pose graph and stereo members are kept as declarations so that the class
-// stays source-compatible with its callers.
+// Pose members (SetPose, UpdatePoseMatrices, GetCameraCenter, GetRotationInverse and
+// the matrices behind them) are implemented as in src/Frame.cc:80-84,146-166;
+// isInFrustum is declared and, as in the fork, defined nowhere; stereo members
+// are kept as data only.
 #ifndef FRAME_H
 #define FRAME_H
 
@@ -40,7 +42,11 @@ public:
     void ExtractORB(int flag, const cv::Mat& im);  // src/Frame.cc:71-77
     // include/Frame.h:36 (declared only in the fork; body as KeyFrame::ComputeBoW, src/KeyFrame.cc:145-152)
     void ComputeBoW();
-    void SetPose(cv::Mat Tcw);
+    void SetPose(cv::Mat Tcw);                       // src/Frame.cc:80-84
+    void UpdatePoseMatrices();                       // src/Frame.cc:146-166
+    inline cv::Mat GetCameraCenter() { return mOw.clone(); }      // include/Frame.h:42-45
+    inline cv::Mat GetRotationInverse() { return mRwc.clone(); }  // include/Frame.h:47-50
+    bool isInFrustum(MapPoint* pMP, float viewingCosLimit);       // include/Frame.h:52 (no body in the fork either)
     bool PosInGrid(const cv::KeyPoint& kp, int& posX, int& posY);
     // src/Frame.cc:86-144.  Host-side accessor for callers that want the index list itself;
     // the Search* kernels run the same query on the device.
@@ -81,6 +87,11 @@ private:
     void UndistortKeyPoints();
     void ComputeImageBounds(const cv::Mat& imLeft);
     void AssignFeaturesToGrid();
+
+    cv::Mat mRcw;  // rotation world -> camera, include/Frame.h:127-130
+    cv::Mat mtcw;  // translation world -> camera
+    cv::Mat mRwc;  // rotation camera -> world
+    cv::Mat mOw;   // camera centre in world coordinates
 };
 
 }  // namespace ORB_SLAM2

@@ -34,22 +34,31 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
     readEnv();
     mQuirks = gQuirks;
     mDevice = gDevice;
-    // The tables only depend on the constructor arguments; a small context provides them
-    // (the device context is re-created on the first frame, sized for that frame).
-    EnsureContext(640, 480);
+    // The tables depend on the constructor arguments alone (host arithmetic); the device context is
+    // created by the first frame, sized for that frame.
+    orb_params p;
+    memset(&p, 0, sizeof(p));
+    p.nfeatures = nfeatures;
+    p.scale_factor = (float)scaleFactor;
+    p.nlevels = nlevels;
+    p.ini_th_fast = iniThFAST;
+    p.min_th_fast = minThFAST;
+    p.quirks = mQuirks;
     mvScaleFactor.resize(nlevels);
     mvInvScaleFactor.resize(nlevels);
     mvLevelSigma2.resize(nlevels);
     mvInvLevelSigma2.resize(nlevels);
     mnFeaturesPerLevel.resize(nlevels);
     umax.resize(16);
-    if (orb_get_tables(mpCtx, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(),
-                       mvInvLevelSigma2.data(), mnFeaturesPerLevel.data(), umax.data()))
-        fail("orb_get_tables");
+    if (orb_compute_tables(&p, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(),
+                           mvInvLevelSigma2.data(), mnFeaturesPerLevel.data(), umax.data()))
+        fail("orb_compute_tables");
     mvImagePyramid.resize(nlevels);
 }
 
-ORBextractor::~ORBextractor() { orb_destroy(mpCtx); }
+ORBextractor::~ORBextractor() {
+    if (mpCtx) orb_destroy(mpCtx);
+}
 
 orb_ctx* ORBextractor::EnsureContext(int width, int height) {
     if (mpCtx && width <= mCtxW && height <= mCtxH) return mpCtx;
@@ -96,15 +105,28 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
         cv::Mat d = _descriptors.getMat();
         for (int i = 0; i < n; i++) memcpy(d.ptr<unsigned char>(i), mDescBuf.data() + (size_t)i * 32, 32);
     }
-    if (mbKeepPyramid) {
-        for (int l = 0; l < nlevels; l++) {
-            int w = 0, h = 0;
-            if (orb_get_pyramid_level(mpCtx, 0, l, nullptr, 0, &w, &h)) fail("orb_get_pyramid_level");
-            mvImagePyramid[l].create(h, w, CV_8UC1);
-            if (orb_get_pyramid_level(mpCtx, 0, l, mvImagePyramid[l].data, (int)mvImagePyramid[l].step, &w, &h))
-                fail("orb_get_pyramid_level");
-        }
+    mbPyramidCurrent = false;
+    if (mbKeepPyramid) DownloadPyramid();
+}
+
+void ORBextractor::DownloadPyramid() {
+    std::vector<unsigned char*> dst(nlevels);
+    std::vector<int> step(nlevels);
+    for (int l = 0; l < nlevels; l++) {
+        int w = 0, h = 0;
+        if (orb_get_pyramid_level(mpCtx, 0, l, nullptr, 0, &w, &h)) fail("orb_get_pyramid_level");
+        mvImagePyramid[l].create(h, w, CV_8UC1);
+        dst[l] = mvImagePyramid[l].data;
+        step[l] = (int)mvImagePyramid[l].step;
     }
+    if (orb_get_pyramid(mpCtx, 0, dst.data(), step.data())) fail("orb_get_pyramid");  // one synchronisation for all levels
+    mbPyramidCurrent = true;
+}
+
+const std::vector<cv::Mat>& ORBextractor::GetImagePyramid() {
+    if (!mpCtx) throw std::runtime_error("GetImagePyramid: no frame has been extracted yet");
+    if (!mbPyramidCurrent) DownloadPyramid();
+    return mvImagePyramid;
 }
 
 }  // namespace ORB_SLAM2

@@ -35,16 +35,22 @@ public:
     std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-    // Level images of the last frame (the ROI part of the reference's padded buffers),
-    // downloaded after every extraction unless SetKeepPyramid(false) was called.
+    // Level images of the last frame (the ROI part of the reference's padded buffers,
+    // include/ORBextractor.h:71).  Nothing on the front-end path reads them, and copying eight
+    // levels back from the device costs more than the extraction of a 640x480 frame, so the member
+    // is filled on request: GetImagePyramid() downloads the levels of the last frame (once per
+    // frame); code that reads the member directly calls SetKeepPyramid(true) first, after which
+    // every operator() fills it as the reference does.
     std::vector<cv::Mat> mvImagePyramid;
 
     // ---- additions (no counterpart in the reference) -------------------------------
     void SetKeepPyramid(bool keep) { mbKeepPyramid = keep; }
+    const std::vector<cv::Mat>& GetImagePyramid();
     // Behaviour preset and device for extractors constructed afterwards
     // (ORB_QUIRKS_FORK by default; also read from ORBHIP_QUIRKS / ORBHIP_DEVICE).
     static void SetDefaults(unsigned quirks, int device);
-    orb_ctx* Context() { return mpCtx; }  // for ORBmatcher, which shares the device state
+    // for Frame and ORBmatcher, which share the device state (created on the first frame, sized for it)
+    orb_ctx* Context() { return mpCtx ? mpCtx : EnsureContext(640, 480); }
     unsigned Quirks() const { return mQuirks; }
     orb_ctx* EnsureContext(int width, int height);
 
@@ -60,7 +66,9 @@ protected:
 
     orb_ctx* mpCtx = nullptr;
     int mCtxW = 0, mCtxH = 0;
-    bool mbKeepPyramid = true;
+    bool mbKeepPyramid = false;
+    bool mbPyramidCurrent = false;  // mvImagePyramid holds the last frame's levels
+    void DownloadPyramid();
     unsigned mQuirks;
     int mDevice;
     std::vector<unsigned char> mKpBuf, mDescBuf;

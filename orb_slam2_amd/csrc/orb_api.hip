@@ -551,7 +551,10 @@ extern "C" int orb_create(const orb_params* prm, orb_ctx** out) {
         }                                                                                             \
     } while (0)
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (int i = 0; i < ORB_MAX_PARTS - 1; i++) {
+    // one extra stream per frame group beyond the first: a process has few hardware queues (four by default),
+    // and streams that share one serialise, so a context takes no more than it will use
+    if (const char* e = getenv("ORBHIP_PARTS")) c->parts = std::max(1, std::min(ORB_MAX_PARTS, atoi(e)));
+    for (int i = 0; i < c->parts - 1; i++) {
         CREATE_TRY(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
         CREATE_TRY(hipEventCreateWithFlags(&c->evJoin[i], hipEventDisableTiming));
     }
@@ -566,7 +569,6 @@ extern "C" int orb_create(const orb_params* prm, orb_ctx** out) {
         }
         *(volatile int*)c->pinSeen.p = 0;
     }
-    if (const char* e = getenv("ORBHIP_PARTS")) c->parts = std::max(1, std::min(ORB_MAX_PARTS, atoi(e)));
     // size everything for the largest announced frame and batch now, so steady-state calls allocate nothing
     int rc = compute_geom(c, prm->max_width, prm->max_height);
     if (rc == ORB_OK) rc = ensure_buffers(c, prm->max_batch);
@@ -635,6 +637,18 @@ extern "C" int orb_get_tables(const orb_ctx* c, float* scale, float* inv_scale, 
     if (umax)
         for (int i = 0; i < 16; i++) umax[i] = c->umax[i];
     return ORB_OK;
+}
+
+extern "C" int orb_compute_tables(const orb_params* prm, float* scale, float* inv_scale, float* sigma2,
+                                  float* inv_sigma2, int* per_level, int* umax) {
+    if (!prm || prm->nlevels < 1 || prm->nlevels > ORB_MAX_LEVELS || !(prm->scale_factor > 1.f) || prm->nfeatures < 1) {
+        orb_set_error("orb_compute_tables: bad parameters");
+        return ORB_ERR_INVALID;
+    }
+    orb_ctx tmp;  // host members only; no device call is made
+    tmp.prm = *prm;
+    build_tables(&tmp);
+    return orb_get_tables(&tmp, scale, inv_scale, sigma2, inv_sigma2, per_level, umax);
 }
 
 // Sends the device's largest-key-count word towards the host, unless an earlier copy is still under way.
@@ -928,6 +942,41 @@ extern "C" int orb_extract(orb_ctx* c, const uint8_t* img, int w, int h, int str
     return orb_extract_batch(c, one, 1, w, h, stride, kps, desc, cap, n_out);
 }
 
+// Levels [l0, l1) of one frame of the last batch to host memory.  A two-dimensional copy into pageable memory
+// goes row by row through the runtime (2 ms per level); instead every level's pitched block is sent to page-locked
+// staging by the DMA engine, all levels in flight together, and the rows are unpacked on the host.
+static int download_levels(orb_ctx* c, int frame, int l0, int l1, uint8_t* const* dst, const int* dstStride) {
+    const OrbGeom& g = c->geom;
+    HIP_TRY(hipSetDevice(c->prm.device));
+    HIP_TRY(hipDeviceSynchronize());  // the batch may have run on the caller's stream
+    size_t total = 0;
+    size_t off[ORB_MAX_LEVELS];
+    for (int l = l0; l < l1; l++) {
+        const OrbLevel& L = g.lv[l];
+        const size_t pitch = l == 0 ? (size_t)c->lastStride0 : (size_t)L.pitch;
+        off[l] = total;
+        total += (pitch * (size_t)(L.h - 1) + (size_t)L.w + 255) & ~(size_t)255;
+    }
+    int rc = c->pinOut.ensure(total);
+    if (rc) return rc;
+    for (int l = l0; l < l1; l++) {
+        const OrbLevel& L = g.lv[l];
+        const uint8_t* src = l == 0 ? c->lastImg0 + (int64_t)frame * c->lastFrameStride0
+                                    : (const uint8_t*)c->dPyr.p + L.off + (int64_t)frame * L.frameStride;
+        const size_t pitch = l == 0 ? (size_t)c->lastStride0 : (size_t)L.pitch;
+        HIP_TRY(hipMemcpyAsync((uint8_t*)c->pinOut.p + off[l], src, pitch * (size_t)(L.h - 1) + (size_t)L.w,
+                               hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int l = l0; l < l1; l++) {
+        const OrbLevel& L = g.lv[l];
+        const size_t pitch = l == 0 ? (size_t)c->lastStride0 : (size_t)L.pitch;
+        const uint8_t* ps = (const uint8_t*)c->pinOut.p + off[l];
+        for (int r = 0; r < L.h; r++) memcpy(dst[l] + (size_t)r * dstStride[l], ps + (size_t)r * pitch, (size_t)L.w);
+    }
+    return ORB_OK;
+}
+
 extern "C" int orb_get_pyramid_level(orb_ctx* c, int frame, int level, uint8_t* dst, int dst_stride, int* w, int* h) {
     if (!c || !c->geomValid || !c->lastImg0) {
         orb_set_error("no batch has been extracted yet");
@@ -946,19 +995,29 @@ extern "C" int orb_get_pyramid_level(orb_ctx* c, int frame, int level, uint8_t* 
         orb_set_error("dst_stride %d < level width %d", dst_stride, L.w);
         return ORB_ERR_INVALID;
     }
-    HIP_TRY(hipSetDevice(c->prm.device));
-    HIP_TRY(hipDeviceSynchronize());
-    const uint8_t* src;
-    int pitch;
-    if (level == 0) {
-        src = c->lastImg0 + (int64_t)frame * c->lastFrameStride0;
-        pitch = c->lastStride0;
-    } else {
-        src = (const uint8_t*)c->dPyr.p + L.off + (int64_t)frame * L.frameStride;
-        pitch = L.pitch;
+    uint8_t* dsts[ORB_MAX_LEVELS] = {};
+    int strides[ORB_MAX_LEVELS] = {};
+    dsts[level] = dst;
+    strides[level] = dst_stride;
+    return download_levels(c, frame, level, level + 1, dsts, strides);
+}
+
+extern "C" int orb_get_pyramid(orb_ctx* c, int frame, uint8_t* const* dst, const int* dst_stride) {
+    if (!c || !c->geomValid || !c->lastImg0 || !dst || !dst_stride) {
+        orb_set_error(!c || !dst || !dst_stride ? "orb_get_pyramid: null argument" : "no batch has been extracted yet");
+        return ORB_ERR_INVALID;
     }
-    HIP_TRY(hipMemcpy2D(dst, dst_stride, src, pitch, L.w, L.h, hipMemcpyDeviceToHost));
-    return ORB_OK;
+    const OrbGeom& g = c->geom;
+    if (frame < 0 || frame >= c->lastFrames) {
+        orb_set_error("frame %d out of range", frame);
+        return ORB_ERR_INVALID;
+    }
+    for (int l = 0; l < g.nlevels; l++)
+        if (!dst[l] || dst_stride[l] < g.lv[l].w) {
+            orb_set_error("level %d: null destination or stride %d < width %d", l, dst_stride[l], g.lv[l].w);
+            return ORB_ERR_INVALID;
+        }
+    return download_levels(c, frame, 0, g.nlevels, dst, dst_stride);
 }
 
 extern "C" int orb_debug_get_fast_keys(orb_ctx* c, int frame, int level, int* xs, int* ys, int* scores, int cap,

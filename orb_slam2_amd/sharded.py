@@ -58,8 +58,14 @@ class ShardedBruteForce:
         if world == 1:
             gathered = packed.reshape(1, -1)
         else:
-            gathered = torch.empty((world, packed.numel()), dtype=packed.dtype, device=packed.device)
-            dist.all_gather_into_tensor(gathered.view(-1), packed.contiguous(), group=self.group)
+            if packed.is_cuda and dist.get_backend(self.group) == "gloo":
+                # gloo moves host memory only (dry runs of several ranks on one GPU): through the host and back
+                host = torch.empty((world, packed.numel()), dtype=packed.dtype)
+                dist.all_gather_into_tensor(host.view(-1), packed.cpu().contiguous(), group=self.group)
+                gathered = host.to(packed.device)
+            else:
+                gathered = torch.empty((world, packed.numel()), dtype=packed.dtype, device=packed.device)
+                dist.all_gather_into_tensor(gathered.view(-1), packed.contiguous(), group=self.group)
         return self.merge(gathered)
 
 

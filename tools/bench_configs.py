@@ -48,13 +48,15 @@ def extraction(cfg, w, h, nf, batch, steps, distinct):
     return ctx, dt, ms, (d_kps, d_desc, d_cnt), frames
 
 
-def main():
-    out = []
+def config2():
     ctx, dt, ms, _, _ = extraction(2, 1241, 376, 2000, 64, 10, 16)
-    out.append({"config": 2, "workload": "64 x 1241x376, nFeatures 2000", "frames_per_s": round(64 / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "stage_ms": ms})
     ctx.close()
+    return {"config": 2, "workload": "64 x 1241x376, nFeatures 2000", "frames_per_s": round(64 / dt, 1),
+            "ms_per_batch": round(dt * 1e3, 3), "stage_ms": {k: round(v, 4) for k, v in ms.items()}}
 
-    # config 3: pairs = (frame, shifted frame); both halves extracted in one batch of 128
+
+def config3():
+    # pairs = (frame, shifted frame); both halves extracted in one batch of 128
     w, h, npairs = 752, 480, 64
     a = [synth_scene(w, h, frame_seed(3, p)) for p in range(8)]
     b = [synth_scene(w, h, frame_seed(3, p), shift=(3, 2), noise_seed=frame_seed(3, p) + 1) for p in range(8)]
@@ -80,18 +82,24 @@ def main():
     dt_ext = timed(lambda: ctx.extract_batch_device(d_imgs, d_kps, d_desc, d_cnt), 10)
     ctx.check_last_batch()
     n1 = d_cnt[:npairs].cpu().numpy()
-    lvl0 = (d_kps[:npairs].view(torch.int32).view(2 * npairs // 2, cap, 7)[:, :, 5] == 0)
-    out.append({"config": 3, "workload": "64 pairs 752x480: extraction (2000 feats) + SearchForInitialization(100, 0.9)",
-                "pairs_per_s": round(npairs / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "extract_ms": round(dt_ext * 1e3, 3),
-                "match_ms": round((dt - dt_ext) * 1e3, 3), "mean_matches": float(d_nm.float().mean().item()),
-                "mean_keypoints": float(n1.mean())})
+    # comparisons of one pair's SearchForInitialization: candidates of its level-0 queries
+    res = {"config": 3, "workload": "64 pairs 752x480: extraction (2000 feats) + SearchForInitialization(100, 0.9)",
+           "pairs_per_s": round(npairs / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "extract_ms": round(dt_ext * 1e3, 3),
+           "match_ms": round((dt - dt_ext) * 1e3, 3), "mean_matches": float(d_nm.float().mean().item()),
+           "mean_keypoints": float(n1.mean())}
     ctx.close()
+    return res
 
+
+def config4():
     ctx, dt, ms, _, _ = extraction(4, 3840, 2160, 4000, 64, 5, 2)
-    out.append({"config": 4, "workload": "64 x 3840x2160 per step, nFeatures 4000 (1024-frame job = 16 such steps per GPU)",
-                "frames_per_s": round(64 / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "stage_ms": ms})
     ctx.close()
-    for o in out:
+    return {"config": 4, "workload": "64 x 3840x2160 per step, nFeatures 4000 (1024-frame job = 16 such steps per GPU)",
+            "frames_per_s": round(64 / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "stage_ms": {k: round(v, 4) for k, v in ms.items()}}
+
+
+def main():
+    for o in (config2(), config3(), config4()):
         print(json.dumps(o))
 
 
