@@ -319,6 +319,36 @@ int orb_bf_query_packed_noalloc(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t
 int orb_bf_merge_packed_device(int device, const uint64_t* d_gathered, int nshards, int nq, int32_t* d_best_idx,
                                uint16_t* d_best_dist, uint16_t* d_second_dist, void* stream);
 
+/* ---- several GPUs of one node from one process ------------------------------------
+ * (No counterpart in the reference, whose front end runs on one thread.)
+ *
+ * Brute force: the database is split into contiguous row blocks, one per entry
+ * of `devices`; every device scans its block for all queries, the per-query
+ * packed words are exchanged with one all-gather of nq x 8 bytes per device
+ * (RCCL's ncclAllGather over xGMI; librccl.so.1 is opened when the object is
+ * created) and merged on every device.  The result equals orb_bf_query_top2 on
+ * the whole database, ties across blocks included.  A device may be listed more
+ * than once (then, or with ORBHIP_EXCHANGE=copy in the environment, the words
+ * travel by device-to-device copies instead of RCCL): that is how one GPU
+ * stands in for several in tests.  Calls on one object must not overlap. */
+typedef struct orb_bf_multi orb_bf_multi;
+int orb_bf_multi_create(const int* devices, int ndev, orb_bf_multi** out);
+void orb_bf_multi_destroy(orb_bf_multi* m);
+/* 1: RCCL all-gather, 0: device-to-device copies. */
+int orb_bf_multi_exchange(const orb_bf_multi* m);
+/* n x 32 bytes in host memory; block r = rows [r n / R, (r + 1) n / R), uploaded by one host thread per device. */
+int orb_bf_multi_set_database(orb_bf_multi* m, const uint8_t* db, int64_t n);
+int orb_bf_multi_query_top2(orb_bf_multi* m, const uint8_t* q, int nq, int32_t* best_idx, uint16_t* best_dist,
+                            uint16_t* second_dist);
+
+/* Frames: orb_extract_batch over n frames split into contiguous blocks
+ * [r n / nctx, (r + 1) n / nctx), block r on ctxs[r] (distinct contexts, one per
+ * device, each created with max_batch >= its block), one host thread per
+ * context, no exchange.  Outputs as orb_extract_batch: the result does not
+ * depend on nctx. */
+int orb_extract_batch_multi(orb_ctx* const* ctxs, int nctx, const uint8_t* const* imgs, int n, int w, int h, int stride,
+                            orb_keypoint* kps, uint8_t* desc, int cap_per_frame, int* n_out);
+
 /* ---- bag of words: DBoW2 vocabulary tree and SearchByBoW ----------------------- */
 
 /* TemplatedVocabulary<FORB::TDescriptor, FORB> (ORBVocabulary, include/ORBVocabulary.h;

@@ -31,6 +31,8 @@ EXPORTS = [
     "orb_debug_get_fast_keys", "orb_resize", "orb_gaussian_blur", "orb_hamming", "orb_match_window",
     "orb_match_window_batch_device", "orb_match_reserve_candidates", "orb_match_projected", "orb_bf_create", "orb_bf_destroy", "orb_bf_set_database",
     "orb_bf_set_database_device", "orb_bf_query_top2", "orb_bf_query_packed_device", "orb_bf_query_packed_noalloc", "orb_bf_merge_packed_device",
+    "orb_bf_multi_create", "orb_bf_multi_destroy", "orb_bf_multi_exchange", "orb_bf_multi_set_database",
+    "orb_bf_multi_query_top2", "orb_extract_batch_multi",
     "orb_enable_stage_timing", "orb_get_stage_timings", "orb_last_error", "orb_version",
     "orb_distinctive_descriptors", "orb_distinctive_descriptors_device",
     "orb_undistort_keypoints", "orb_undistort_keypoints_device", "orb_compute_image_bounds", "orb_set_image_bounds",
@@ -421,6 +423,52 @@ class BruteForce:
     def query_packed_noalloc(self, d_q, d_packed, stream=None):
         """The same through the entry point that allocates nothing (fixed partials block in the library)."""
         _check(lib().orb_bf_query_packed_noalloc(self.h, _dp(d_q), d_q.shape[0], _dp(d_packed), _stream(stream)))
+
+
+class MultiBruteForce:
+    """Brute-force top-2 over a database row-sharded over several devices of this process (RCCL all-gather)."""
+
+    def __init__(self, devices):
+        self.h = C.c_void_p()
+        self._destroy = lib().orb_bf_multi_destroy
+        devs = (C.c_int * len(devices))(*devices)
+        _check(lib().orb_bf_multi_create(devs, len(devices), C.byref(self.h)))
+        self.exchange = "rccl" if lib().orb_bf_multi_exchange(self.h) == 1 else "copy"
+
+    def close(self):
+        if getattr(self, "h", None) and self.h:
+            self._destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def set_database(self, db):
+        db = np.ascontiguousarray(db, np.uint8)
+        _check(lib().orb_bf_multi_set_database(self.h, _p(db), C.c_int64(len(db))))
+
+    def query_top2(self, q):
+        q = np.ascontiguousarray(q, np.uint8)
+        nq = len(q)
+        idx = np.zeros(nq, np.int32)
+        d1 = np.zeros(nq, np.uint16)
+        d2 = np.zeros(nq, np.uint16)
+        _check(lib().orb_bf_multi_query_top2(self.h, _p(q), nq, _p(idx), _p(d1), _p(d2)))
+        return idx, d1, d2
+
+
+def extract_batch_multi(contexts, imgs):
+    """orb_extract_batch_multi: contiguous frame blocks over several contexts (one per device)."""
+    imgs = [np.ascontiguousarray(i, np.uint8) for i in imgs]
+    n = len(imgs)
+    h, w = imgs[0].shape
+    cap = contexts[0].cap
+    ptrs = (C.c_void_p * n)(*[i.ctypes.data for i in imgs])
+    hs = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+    kps = np.zeros((n, cap), KP_DTYPE)
+    desc = np.zeros((n, cap, 32), np.uint8)
+    cnt = np.zeros(n, np.int32)
+    _check(lib().orb_extract_batch_multi(hs, len(contexts), ptrs, n, w, h, imgs[0].strides[0], _p(kps), _p(desc), cap, _p(cnt)))
+    return [(kps[f, : cnt[f]].copy(), desc[f, : cnt[f]].copy()) for f in range(n)]
 
 
 def merge_packed_device(device, d_gathered, nshards, nq, d_idx, d_best, d_second, stream=None):
