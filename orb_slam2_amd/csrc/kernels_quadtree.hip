@@ -1,54 +1,81 @@
 // DistributeOctTree for every (frame, level) of a batch: one workgroup each.
-// The algorithm itself is in quadtree_core.h.  This kernel first turns the
-// level's FAST keys (per-cell slots) into sort entries numbered in the
-// reference's order (src/ORBextractor.cc:825-870: cell rows, cells, rows inside
-// the cell), then sorts them by quadtree path, runs the distribution and
-// writes the winners in list order.
+// The algorithm itself is in quadtree_core.h.
 //
-// Levels of everyday frame sizes keep the sorted keys and all node scratch in
-// LDS; larger ones (a 4K level holds ~1e5 keys) use the global-memory buffers
-// of the same layout.  The kernel is bound by latency, not by issue rate, so
-// its speed is proportional to the workgroups a CU can hold: the LDS block is
-// sized per launch (QtLaunch) to what the levels of that launch need.
+// Fast path (histogram form): the level's FAST keys are never sorted or even
+// gathered.  One pass over the per-cell key slots counts them into buckets =
+// quadtree cells of a fixed depth and keeps the best key of every bucket (LDS
+// atomics); the distribution then works on the prefix sums of the counts, and
+// the winner of a node is the best entry over its buckets.  That is exact as
+// long as no node with several keys has to be divided below the bucket depth,
+// which the depth is chosen to make rare (qt_hist_depth).
+//
+// Slow path (sorted form), taken by a level only when the fast path reports
+// such a node: the keys are turned into sort entries numbered in the
+// reference's order (src/ORBextractor.cc:825-870: cell rows, cells, rows inside
+// the cell), sorted by quadtree path in global memory, and distributed by
+// binary searches over the sorted array.  Same result by construction (both
+// forms are checked against the oracle's std::list restatement, tests/emu).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 
 #include "quadtree_core.h"
 
+#ifdef QT_PROFILE
+__device__ unsigned long long g_qtProfile[32];
+extern "C" int orb_debug_quadtree_profile(unsigned long long* out, int clear) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qtProfile), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    if (clear) {
+        unsigned long long z[32] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_qtProfile), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
 #define QT_MAX_THREADS 1024
+#define QT_CELLS_IN_FLIGHT 8   // cells whose loads a lane group of the counting pass has under way at once
 #define QT_LDS_KEYS_MAX 4096
 #define QT_STATIC_LDS 1024     // bound on sizeof(QtShared)
 
 struct QtLaunch {
     int level0, nlevels;  // levels [level0, level0 + nlevels) of every frame
-    int ldsKeys;          // sort entries the LDS block holds
-    int binBits;          // key-sort buckets = 2^binBits
-    int regionInts;       // ints behind the keys: bucket arrays, then node scratch
+    int ldsKeys;          // sort entries the LDS block holds (sorted form; 0: the sorted keys stay in global memory)
+    int binBits;          // key-sort buckets = 2^binBits (sorted form)
+    int regionInts;       // ints behind the keys: histogram or bucket arrays, then node scratch
     unsigned nframesMagic;  // orb_div_magic(frames of the launch)
 };
 
-// Sort, distribute, select and emit one level.  Inlined once per memory placement so that the
-// compiler sees which address space `sorted` and the node scratch live in.
-static __device__ __forceinline__ int qt_level(const OrbGeom* g, const OrbLevel& L, const unsigned long long* tmp,
-                                               unsigned long long* sorted, const QtWork& w0, int n,
-                                               const uint32_t* __restrict__ levelCellKeys, uint32_t* __restrict__ selXY,
-                                               int* __restrict__ selScore, int* __restrict__ error, const QtBins bins,
-                                               QtShared* sh) {
+// Path of a key from its rank (= cell * cellCap + position inside the cell): the histogram form needs it for
+// single keys below the bucket depth.
+struct QtDevRankCode {
+    const uint32_t* lck;
+    const uint32_t* codeX;
+    const uint32_t* codeY;
+    int cellCap, nCols, wCell, hCell;
+    unsigned cellCapMagic, nColsMagic;
+    __device__ __forceinline__ uint32_t operator()(uint32_t rank) const {
+        const uint32_t key = lck[rank];
+        const int cell = (int)orb_div(rank, (unsigned)cellCap, cellCapMagic);
+        const int ci = (int)orb_div((unsigned)cell, (unsigned)nCols, nColsMagic), cj = cell - ci * nCols;
+        return codeX[3 + cj * wCell + (int)(key & 0xff)] | codeY[3 + ci * hCell + (int)((key >> 8) & 0xff)];
+    }
+};
+
+// Winners of the final list -> selXY / selScore in list order.
+template <class Space>
+static __device__ __forceinline__ int qt_finish(const OrbGeom* g, const OrbLevel& L, const Space& sp, const QtWork& w,
+                                                OrbNode* list, int count, const uint32_t* __restrict__ levelCellKeys,
+                                                uint32_t* __restrict__ selXY, int* __restrict__ selScore,
+                                                int* __restrict__ error, QtShared* sh) {
     const int t = threadIdx.x, T = (int)blockDim.x;
-    qt_sort_keys(tmp, sorted, n, L.nIni, bins, sh);
-    __syncthreads();  // the bucket arrays may now be reused as node scratch
-    QtWork w = w0;
-    w.sorted = sorted;
-    OrbNode* list = nullptr;
-    int count = 0;
-    qt_distribute(w, n, L.nIni, L.quota, (g->quirks & ORB_Q_DIVIDE_N3) ? 1 : 0, sh, &list, &count);
     if (sh->err && t == 0) atomicOr(error, sh->err == 2 ? 8 : 16);
     if (count > L.outCap) {  // cannot happen (quota + 2 bound); fail loudly, never truncate silently
         if (t == 0) atomicOr(error, 32);
         count = L.outCap;
     }
-    qt_select_all(sorted, list, count, w.scanA, sh);
+    qt_select_all(sp, list, count, w.scanA, sh);
+    QT_STAMP(6);
     for (int i = t; i < count; i += T) {
         const int rank = w.scanA[i];
         const uint32_t key = levelCellKeys[rank];  // rank = cell * cellCap + position inside the cell
@@ -62,9 +89,51 @@ static __device__ __forceinline__ int qt_level(const OrbGeom* g, const OrbLevel&
     return count;
 }
 
+// Sorted form: sort, distribute, select and emit one level.  Inlined once per memory placement so that the
+// compiler sees which address space `sorted` and the node scratch live in.
+static __device__ __forceinline__ int qt_level(const OrbGeom* g, const OrbLevel& L, const unsigned long long* tmp,
+                                               unsigned long long* sorted, const QtWork& w0, int n,
+                                               const uint32_t* __restrict__ levelCellKeys, uint32_t* __restrict__ selXY,
+                                               int* __restrict__ selScore, int* __restrict__ error, const QtBins bins,
+                                               QtShared* sh) {
+    qt_sort_keys(tmp, sorted, n, L.nIni, bins, sh);
+    __syncthreads();  // the bucket arrays may now be reused as node scratch
+    QT_STAMP(4);
+    QtWork w = w0;
+    w.sorted = sorted;
+    const QtSortedSpace sp = {sorted, n};
+    OrbNode* list = nullptr;
+    int count = 0;
+    qt_distribute(sp, w, L.nIni, L.quota, (g->quirks & ORB_Q_DIVIDE_N3) ? 1 : 0, sh, &list, &count);
+    QT_STAMP(5);
+    return qt_finish(g, L, sp, w, list, count, levelCellKeys, selXY, selScore, error, sh);
+}
+
+// Node scratch of a (frame, level) in the global buffers.
+static __device__ __forceinline__ void qt_work_global(QtWork* w, const OrbGeom* g, const OrbLevel& L, int frame, int level,
+                                                      OrbNode* nodes, int* ints) {
+    OrbNode* nb = nodes + ((int64_t)frame * g->nodesPerFrame + L.nodeBase) * 2;
+    int* p = ints + ((int64_t)frame * g->nodesPerFrame + L.nodeBase) * 9 + (int64_t)(frame * g->nlevels + level) * 4;
+    w->nodeCap = L.nodeCap;
+    w->listA = nb;
+    w->listB = nb + L.nodeCap;
+    w->rec = p;
+    p += L.nodeCap;
+    w->recSorted = p;
+    p += L.nodeCap;
+    w->bounds = p;
+    p += 4 * L.nodeCap;
+    w->scanA = p;
+    p += L.nodeCap + 1;
+    w->scanB = p;
+    p += L.nodeCap + 1;
+    w->scanC = p;
+}
+
 __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __restrict__ g, const QtLaunch q, int frame0, int nframes,
                                                         const uint32_t* __restrict__ cellKeys,
                                                         const int* __restrict__ cellCount,
+                                                        const uint32_t* __restrict__ codeTab,
                                                         unsigned long long* __restrict__ sortBuf,
                                                         OrbNode* __restrict__ nodes, int* __restrict__ ints,
                                                         uint32_t* __restrict__ selXY, int* __restrict__ selScore,
@@ -86,12 +155,112 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __re
     unsigned long long* tmp = sortedG + L.keyCap;
     const uint32_t* lck = cellKeys + ((int64_t)frame * g->cellsPerFrame + L.cellBase) * g->cellCap;
 
+    const int* cc = cellCount + (int64_t)frame * g->cellsPerFrame + L.cellBase;
+    const int nCells = L.nCols * L.nRows, cellCap = g->cellCap;
+    const uint32_t* codeX = codeTab + L.codeTabX;  // quadtree path words of the level's columns and rows
+    const uint32_t* codeY = codeTab + L.codeTabY;
+    const int64_t ob = (int64_t)frame * g->outCapFrame + L.outBase;
+    const int n3quirk = (g->quirks & ORB_Q_DIVIDE_N3) ? 1 : 0;
+    QT_STAMP(0);
+
+    // ---- histogram form ------------------------------------------------------------------------------
+    const int Db = L.histDepth, nb = L.nIni << (2 * Db);
+    if (2 * nb + 1 <= q.regionInts) {
+        int* start = s_region;
+        uint32_t* best = (uint32_t*)(s_region + nb + 1);
+        for (int b = t; b < nb; b += T) {
+            start[b] = 0;
+            best[b] = 0u;
+        }
+        if (t == 0) start[nb] = 0;
+        __syncthreads();
+        // Eight lanes per cell: a cell's keys are consecutive words, and most cells hold fewer than eight.  Eight
+        // cells are in flight per lane group (counts, then first keys, then path words: three dependent loads
+        // whose latency would otherwise be paid cell after cell); keys beyond a cell's first eight follow.
+        const int shiftB = 2 * (ORB_CODE_DEPTH - Db);
+        const int sub = t & 7, ngrp = T >> 3;
+        auto count_key = [&](int c, int k, uint32_t key, int bx, int by) {
+            const uint32_t code = codeX[bx + (int)(key & 0xff)] | codeY[by + (int)((key >> 8) & 0xff)];
+            const uint32_t rank = (uint32_t)(c * cellCap + k);
+            const uint32_t prio = ((key >> 16) << 24) | (~rank & 0xffffffu);  // = qt_entry_prio of the key's sort entry
+            atomicAdd(&start[code >> shiftB], 1);
+            atomicMax(&best[code >> shiftB], prio);
+        };
+        for (int c0 = t >> 3; c0 < nCells; c0 += QT_CELLS_IN_FLIGHT * ngrp) {
+            int cnt[QT_CELLS_IN_FLIGHT], bx[QT_CELLS_IN_FLIGHT], by[QT_CELLS_IN_FLIGHT];
+            uint32_t key[QT_CELLS_IN_FLIGHT];
+#pragma unroll
+            for (int u = 0; u < QT_CELLS_IN_FLIGHT; u++) {
+                const int c = c0 + u * ngrp;
+                cnt[u] = c < nCells ? cc[c] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < QT_CELLS_IN_FLIGHT; u++) {
+                const int c = c0 + u * ngrp;
+                key[u] = sub < cnt[u] ? lck[(int64_t)c * cellCap + sub] : 0u;
+                const int ci = (int)orb_div((unsigned)c, (unsigned)L.nCols, L.nColsMagic), cj = c - ci * L.nCols;
+                bx[u] = 3 + cj * L.wCell;  // relative to the 16-pixel border, as :864-865
+                by[u] = 3 + ci * L.hCell;
+            }
+#pragma unroll
+            for (int u = 0; u < QT_CELLS_IN_FLIGHT; u++)
+                if (sub < cnt[u]) count_key(c0 + u * ngrp, sub, key[u], bx[u], by[u]);
+#pragma unroll
+            for (int u = 0; u < QT_CELLS_IN_FLIGHT; u++) {
+                const int c = c0 + u * ngrp;
+                for (int k = sub + 8; k < cnt[u]; k += 8) count_key(c, k, lck[(int64_t)c * cellCap + k], bx[u], by[u]);
+            }
+        }
+        __syncthreads();
+        QT_STAMP(1);
+        qt_scan(start, nb, &sh);
+        const int n = start[nb];
+        if (t == 0) {
+            levelKeys[frame * nlevels + level] = n;
+            if (n > error[1]) atomicMax(&error[1], n);
+        }
+        if (n > L.keyCap) {  // cannot happen: keyCap is the 2x2-block bound summed over the cells
+            if (t == 0) {
+                atomicOr(error, 4);
+                levelCount[frame * nlevels + level] = 0;
+            }
+            return;
+        }
+        if (n == 0) {
+            if (t == 0) levelCount[frame * nlevels + level] = 0;
+            return;
+        }
+        QtWork w;
+        if (QT_NODE_INTS(L.nodeCap) <= q.regionInts - (2 * nb + 1)) qt_work_from_pool(&w, s_region + 2 * nb + 1, L.nodeCap);
+        else qt_work_global(&w, g, L, frame, level, nodes, ints);
+        w.sorted = nullptr;
+        const QtDevRankCode rc = {lck, codeX, codeY, cellCap, L.nCols, L.wCell, L.hCell, g->cellCapMagic, L.nColsMagic};
+        const QtHistSpace<QtDevRankCode> sp = {start, best, Db, rc};
+        OrbNode* list = nullptr;
+        int count = 0;
+        QT_STAMP(4);
+        qt_distribute(sp, w, L.nIni, L.quota, n3quirk, &sh, &list, &count);
+        QT_STAMP(5);
+        if (!sh.deeper) {
+            count = qt_finish(g, L, sp, w, list, count, lck, selXY + ob, selScore + ob, error, &sh);
+            if (t == 0) levelCount[frame * nlevels + level] = count;
+            QT_STAMP(7);
+#ifdef QT_PROFILE
+            if (blockIdx.x == 0 && t == 0) {
+                g_qtProfile[8] = (unsigned long long)n;
+                g_qtProfile[9] = (unsigned long long)count;
+                g_qtProfile[10] = 2ull;
+            }
+#endif
+            return;
+        }
+        __syncthreads();  // a node below the bucket depth holds several keys: the sorted form takes the level
+    }
+
+    // ---- sorted form ---------------------------------------------------------------------------------
     // Gather: cells are taken in chunks whose key offsets fit the LDS bucket array; every thread then
     // owns keys (not cells), finds each key's cell by binary search over the chunk's offsets and
     // writes its sort entry.  All loads of a thread are independent of each other.
-    const int* cc = cellCount + (int64_t)frame * g->cellsPerFrame + L.cellBase;
-    const int nCells = L.nCols * L.nRows, cellCap = g->cellCap;
-    const int height = L.maxBorderY - ORB_BORDER;
     int n = 0;
     const int chunkCells = 1 << q.binBits;
     for (int c0 = 0; c0 < nCells; c0 += chunkCells) {
@@ -113,14 +282,14 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __re
             const int x = 3 + cj * L.wCell + (int)(key & 0xff);  // relative to the 16-pixel border, as :864-865
             const int y = 3 + ci * L.hCell + (int)((key >> 8) & 0xff);
             if (n + r < L.keyCap)
-                tmp[n + r] = qt_entry(qt_code(x, y, L.nIni, L.hX, height), (uint32_t)(cell * cellCap + k), key >> 16);
+                tmp[n + r] = qt_entry(codeX[x] | codeY[y], (uint32_t)(cell * cellCap + k), key >> 16);
         }
         n += chunk;
         __syncthreads();
     }
     if (t == 0) {
         levelKeys[frame * nlevels + level] = n;
-        if (n > error[1]) atomicMax(&error[1], n);  // sizes the LDS block of later launches
+        if (n > error[1]) atomicMax(&error[1], n);
     }
     if (n > L.keyCap) {  // cannot happen: keyCap is the 2x2-block bound summed over the cells
         if (t == 0) {
@@ -131,92 +300,69 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __re
     }
     int count = 0;
     if (n > 0) {
-        const int64_t ob = (int64_t)frame * g->outCapFrame + L.outBase;
         QtWork w;
         if (n <= q.ldsKeys && QT_NODE_INTS(L.nodeCap) <= q.regionInts) {
             qt_work_from_pool(&w, s_region, L.nodeCap);
             count = qt_level(g, L, tmp, s_keys, w, n, lck, selXY + ob, selScore + ob, error, bins, &sh);
         } else {
-            OrbNode* nb = nodes + ((int64_t)frame * g->nodesPerFrame + L.nodeBase) * 2;
-            int* p = ints + ((int64_t)frame * g->nodesPerFrame + L.nodeBase) * 9 + (int64_t)(frame * nlevels + level) * 4;
-            w.nodeCap = L.nodeCap;
-            w.listA = nb;
-            w.listB = nb + L.nodeCap;
-            w.rec = p;
-            p += L.nodeCap;
-            w.recSorted = p;
-            p += L.nodeCap;
-            w.bounds = p;
-            p += 4 * L.nodeCap;
-            w.scanA = p;
-            p += L.nodeCap + 1;
-            w.scanB = p;
-            p += L.nodeCap + 1;
-            w.scanC = p;
+            if (QT_NODE_INTS(L.nodeCap) <= q.regionInts) qt_work_from_pool(&w, s_region, L.nodeCap);  // (behind the sort's buckets in time)
+            else qt_work_global(&w, g, L, frame, level, nodes, ints);
             count = qt_level(g, L, tmp, sortedG, w, n, lck, selXY + ob, selScore + ob, error, bins, &sh);
         }
     }
     if (t == 0) levelCount[frame * nlevels + level] = count;
 }
 
-// LDS block for levels [level0, level0 + nlevels): the bucket arrays and the largest node pool of these
-// levels share the region behind the keys; levels whose node pool would push the block past 64 KB
-// (quotas in the thousands) run from global memory anyway.
-static QtLaunch qt_plan(const OrbGeom& g, int level0, int nlevels, int ldsKeys) {
+// LDS block of a launch over all levels.  The histogram arrays (2 nb + 1 ints for nb buckets) and the node
+// scratch behind them decide it; the sorted form, which only levels the histogram form gives up on take, puts
+// its bucket arrays over the same words, keeps its sorted keys in global memory and its node scratch wherever
+// the histogram form had it.
+static QtLaunch qt_plan(const OrbGeom& g, bool bigFrames) {
     QtLaunch q;
-    q.level0 = level0;
-    q.nlevels = nlevels;
-    q.ldsKeys = ldsKeys;
-    int pool = 0;
-    for (int l = level0; l < level0 + nlevels; l++) pool = std::max(pool, QT_NODE_INTS(g.lv[l].nodeCap));
-    // about four keys per bucket when the block is full; more buckets when the node pool leaves the room
-    for (int attempt = 0; attempt < 2; attempt++) {
-        int bits = 8;
-        while ((4 << bits) < ldsKeys && bits < QT_MAX_BIN_BITS) bits++;
-        while (bits < QT_MAX_BIN_BITS && QT_BIN_INTS(bits + 1) <= pool) bits++;
-        q.binBits = bits;
-        q.regionInts = std::max(pool, QT_BIN_INTS(bits));
-        if ((size_t)ldsKeys * 8 + (size_t)q.regionInts * 4 + QT_STATIC_LDS <= 65536) break;
-        // such levels use the global buffers: no keys in LDS, and all the buckets the sort can use
-        pool = 0;
-        ldsKeys = 0;
-        q.ldsKeys = 0;
-        q.binBits = QT_MAX_BIN_BITS;
-        q.regionInts = QT_BIN_INTS(QT_MAX_BIN_BITS);
-        break;
+    q.level0 = 0;
+    q.nlevels = g.nlevels;
+    q.ldsKeys = 0;
+    q.nframesMagic = 0;
+    int hist = 0, both = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        const int h = 2 * (g.lv[l].nIni << (2 * g.lv[l].histDepth)) + 1;
+        hist = std::max(hist, h);
+        both = std::max(both, h + QT_NODE_INTS(g.lv[l].nodeCap));
     }
+    // large frames: a workgroup of 1024 threads has its CU to itself, the node scratch of levels with quotas in
+    // the hundreds stays in global memory; otherwise every level's scratch sits behind its histogram
+    const size_t limit = (bigFrames ? 160 : 64) * 1024 - QT_STATIC_LDS;
+    q.regionInts = ((size_t)both * 4 <= limit) ? both : hist;
+    q.binBits = 8;
+    while (q.binBits < (bigFrames ? QT_MAX_BIN_BITS_BIG : QT_MAX_BIN_BITS) && QT_BIN_INTS(q.binBits + 1) <= q.regionInts) q.binBits++;
     return q;
 }
 
 int orb_launch_quadtree(const OrbBatch& b) {
     const OrbGeom& g = *b.h_geom;
     // large levels (4K frames hand ~1e5 keys to the quadtree) get a full 1024-thread workgroup
-    const int threads = g.lv[0].keyCap > 400000 ? 1024 : 256;
-    // keys in LDS: the largest level met so far plus an eighth; the full block until a count has arrived
-    int ldsKeys = QT_LDS_KEYS_MAX;
-    if (b.qtKeysSeen > 0) ldsKeys = std::min(QT_LDS_KEYS_MAX, std::max(512, (b.qtKeysSeen + b.qtKeysSeen / 8 + 63) & ~63));
-    QtLaunch q = qt_plan(g, 0, g.nlevels, ldsKeys);
-    if (q.ldsKeys > 0 && q.ldsKeys < QT_LDS_KEYS_MAX) {
-        // The block decides how many workgroups a CU holds; between two such steps a larger block costs
-        // nothing, so the keys get all the room up to the next step (measured: four blocks of 40 908 bytes
-        // fit the 160 KB of a CU, four of 41 036 do not; sizes are rounded up to 512 bytes here to stay clear
-        // of the allocation granularity).
-        const size_t unit = 512, perCU = 160 * 1024;
-        auto block_bytes = [&](const QtLaunch& p) {
-            return (sizeof(QtShared) + (size_t)p.ldsKeys * 8 + (size_t)p.regionInts * 4 + unit - 1) / unit * unit;
-        };
-        const size_t wgs = perCU / block_bytes(q);
-        if (wgs >= 1) {
-            const size_t room = perCU / wgs / unit * unit;
-            const int more = (int)((room - block_bytes(q)) / 8);
-            const QtLaunch q2 = qt_plan(g, 0, g.nlevels, std::min(QT_LDS_KEYS_MAX, q.ldsKeys + more));
-            if (q2.ldsKeys > 0 && block_bytes(q2) <= room) q = q2;
-        }
-    }
+    const bool bigFrames = g.lv[0].keyCap > ORB_QT_BIG_KEYCAP;
+    const int threads = bigFrames ? 1024 : 256;
+    QtLaunch q = qt_plan(g, bigFrames);
     q.nframesMagic = orb_div_magic((uint32_t)b.nframes, (uint64_t)b.nframes * q.nlevels);
     const size_t lds = (size_t)q.ldsKeys * 8 + (size_t)q.regionInts * 4;
+    if (lds + QT_STATIC_LDS > 160 * 1024) {
+        orb_set_error("internal: quadtree LDS block of %zu bytes", lds);
+        return ORB_ERR_UNSUPPORTED;
+    }
+    if (lds > 64 * 1024) {  // more dynamic LDS than the default per-workgroup limit: ask for it (once per process is enough)
+        static bool asked = false;
+        if (!asked) {
+            hipError_t ea = hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - QT_STATIC_LDS);
+            if (ea != hipSuccess) {
+                orb_set_error("quadtree: %zu bytes of LDS per workgroup refused: %s", lds, hipGetErrorString(ea));
+                return ORB_ERR_HIP;
+            }
+            asked = true;
+        }
+    }
     hipLaunchKernelGGL(k_quadtree, dim3(b.nframes * q.nlevels), dim3(threads), lds, (hipStream_t)b.stream, b.d_geom, q,
-                       b.frame0, b.nframes, b.d_cellKeys, b.d_cellCount, b.d_sort, b.d_nodes, b.d_ints, b.d_selXY, b.d_selScore, b.d_levelCount,
+                       b.frame0, b.nframes, b.d_cellKeys, b.d_cellCount, b.d_codeTab, b.d_sort, b.d_nodes, b.d_ints, b.d_selXY, b.d_selScore, b.d_levelCount,
                        b.d_levelKeys, b.d_error);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "orb_internal.h"
+#include "quadtree_core.h"  // qt_code_x / qt_code_y for the path tables
 
 // ---- error reporting ----------------------------------------------------------------
 static thread_local char t_err[512] = "";
@@ -98,6 +99,7 @@ struct orb_ctx {
     bool geomValid = false;
     std::vector<OrbAreaTap> areaTaps;
     std::vector<OrbLinTap> linTaps;
+    std::vector<uint32_t> codeTab;  // quadtree path words per column / row of every level
     hipStream_t stream = nullptr;
     // A batch is enqueued as up to ORB_MAX_PARTS groups of frames, the first on the caller's stream and
     // the others on these, so that the latency-bound stages of one group (quadtree, small pyramid
@@ -105,7 +107,7 @@ struct orb_ctx {
     hipStream_t aux[ORB_MAX_PARTS - 1] = {};
     hipEvent_t evFork = nullptr, evJoin[ORB_MAX_PARTS - 1] = {};
     int parts = 2;
-    DevBuf dGeom, dAreaTaps, dLinTaps, dInput, dPyr, dCellKeys, dCellCount, dSort, dNodes, dInts,
+    DevBuf dGeom, dAreaTaps, dLinTaps, dCodeTab, dInput, dPyr, dCellKeys, dCellCount, dSort, dNodes, dInts,
         dSelXY, dSelScore, dLevelCount, dLevelKeys, dError, dKps, dDesc, dNOut, dTmpA, dTmpB;
     PinBuf pinIn, pinOut;  // host-pointer entry points only, sized on first use
     // The quadtree kernel's LDS block holds a level's keys; how many FAST hands over is only known on the
@@ -434,6 +436,20 @@ static int compute_geom(orb_ctx* c, int w, int h) {
             return ORB_ERR_UNSUPPORTED;
         }
     }
+    // quadtree path words: per level one word per column and one per row of the area FAST keys lie in
+    // (coordinates relative to the 16-pixel border, src/ORBextractor.cc:864-865)
+    std::vector<uint32_t> ct;
+    for (int l = 0; l < g.nlevels; l++) {
+        OrbLevel& L = g.lv[l];
+        const int width = L.maxBorderX - ORB_BORDER, height = L.maxBorderY - ORB_BORDER;
+        L.codeTabX = (int)ct.size();
+        for (int x = 0; x < width; x++) ct.push_back(qt_code_x(x, L.nIni, L.hX));
+        L.codeTabY = (int)ct.size();
+        for (int y = 0; y < height; y++) ct.push_back(qt_code_y(y, height));
+        // buckets of the quadtree's histogram form: 4096 at most where several workgroups share a CU's LDS,
+        // 16384 for the levels of large frames, whose workgroups take a CU for themselves
+        L.histDepth = qt_hist_depth(L.nIni, L.quota, g.lv[0].keyCap > ORB_QT_BIG_KEYCAP ? 16384 : 4096);
+    }
     g.cellsPerFrame = cellBase;
     g.cellCap = cellCap;
     g.outCapFrame = outBase;
@@ -454,12 +470,14 @@ static int compute_geom(orb_ctx* c, int w, int h) {
     c->geom = g;
     c->areaTaps.swap(at);
     c->linTaps.swap(lt);
+    c->codeTab.swap(ct);
     c->geomValid = true;
     c->lastFrames = 0;  // per-batch level offsets must be rebuilt
     int rc;
     if ((rc = c->dGeom.ensure(sizeof(OrbGeom)))) return rc;
     if ((rc = c->dAreaTaps.ensure(std::max<size_t>(1, c->areaTaps.size()) * sizeof(OrbAreaTap)))) return rc;
     if ((rc = c->dLinTaps.ensure(std::max<size_t>(1, c->linTaps.size()) * sizeof(OrbLinTap)))) return rc;
+    if ((rc = c->dCodeTab.ensure(c->codeTab.size() * sizeof(uint32_t)))) return rc;
     // (synchronous copies: geometry only changes when the frame size does)
     HIP_TRY(hipDeviceSynchronize());
     if (!c->areaTaps.empty())
@@ -468,6 +486,7 @@ static int compute_geom(orb_ctx* c, int w, int h) {
     if (!c->linTaps.empty())
         HIP_TRY(hipMemcpy(c->dLinTaps.p, c->linTaps.data(), c->linTaps.size() * sizeof(OrbLinTap),
                           hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->dCodeTab.p, c->codeTab.data(), c->codeTab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     return ORB_OK;
 }
 
@@ -592,7 +611,7 @@ extern "C" void orb_destroy(orb_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->prm.device);
     (void)hipDeviceSynchronize();
-    DevBuf* bufs[] = {&c->dGeom, &c->dAreaTaps, &c->dLinTaps, &c->dInput, &c->dPyr, &c->dCellKeys, &c->dCellCount,
+    DevBuf* bufs[] = {&c->dGeom, &c->dAreaTaps, &c->dLinTaps, &c->dCodeTab, &c->dInput, &c->dPyr, &c->dCellKeys, &c->dCellCount,
                       &c->dSort, &c->dNodes, &c->dInts, &c->dSelXY, &c->dSelScore,
                       &c->dLevelCount, &c->dLevelKeys, &c->dError, &c->dKps, &c->dDesc, &c->dNOut, &c->dTmpA,
                       &c->dTmpB};
@@ -692,6 +711,7 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
     b.d_pyr = (uint8_t*)c->dPyr.p;
     b.d_areaTaps = (const OrbAreaTap*)c->dAreaTaps.p;
     b.d_linTaps = (const OrbLinTap*)c->dLinTaps.p;
+    b.d_codeTab = (const uint32_t*)c->dCodeTab.p;
     b.d_cellKeys = (uint32_t*)c->dCellKeys.p;
     b.d_cellCount = (int*)c->dCellCount.p;
     b.d_sort = (unsigned long long*)c->dSort.p;

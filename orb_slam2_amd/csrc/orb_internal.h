@@ -14,6 +14,7 @@
 #define ORB_GRID_COLS 64        // include/Frame.h:17
 #define ORB_GRID_ROWS 48        // include/Frame.h:16
 #define ORB_HISTO 30            // src/ORBmatcher.cc:18
+#define ORB_QT_BIG_KEYCAP 400000 // level-0 key capacity from which a frame counts as large for the quadtree kernel (4K: 2 million)
 
 // Geometry of one pyramid level for the current frame size.
 struct OrbLevel {
@@ -36,6 +37,8 @@ struct OrbLevel {
     float scale;                // mvScaleFactor[level]
     float patchSize;            // (float)(int)(31 * scale)
     int tabX, tabY;             // first entry of the level's resize taps in the tap table
+    int codeTabX, codeTabY;     // first entry of the level's quadtree path words per column / per row (border-relative)
+    int histDepth;              // bucket depth (path digits) of the quadtree's histogram form, qt_hist_depth
 };
 
 struct OrbGeom {
@@ -177,6 +180,7 @@ struct OrbBatch {  // everything one extraction launch sequence needs
     uint8_t* d_pyr;             // levels >= 1, level-major
     const OrbAreaTap* d_areaTaps;
     const OrbLinTap* d_linTaps;
+    const uint32_t* d_codeTab;  // quadtree path words per column and per row of every level (OrbLevel::codeTabX / codeTabY)
     uint32_t* d_cellKeys;       // [frame][cell][cellCap]: x | y << 8 | score << 16, cell-interior coordinates
     int* d_cellCount;           // [frame][cell]
     unsigned long long* d_sort; // [frame][2 * keysPerFrame]: per level keyCap sorted entries, then keyCap unsorted ones

@@ -46,10 +46,36 @@ static inline int qt_host_fetch_add(int* p, int v) {
 #define QT_ATOMIC_MAX32(p, v) atomicMax((p), (v))
 #endif
 
+// Development aid: with -DQT_PROFILE the first workgroup of a launch stamps the 100 MHz wall clock at phase
+// boundaries into g_qtProfile (kernels_quadtree.hip, read back with orb_debug_quadtree_profile).
+#if defined(QT_PROFILE) && !defined(ORB_HOST_EMU)
+extern __device__ unsigned long long g_qtProfile[32];
+#define QT_STAMP(k)                                                                   \
+    do {                                                                              \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_qtProfile[k] = wall_clock64();     \
+    } while (0)
+#define QT_COUNT(k)                                                       \
+    do {                                                                  \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_qtProfile[k] += 1ull;  \
+    } while (0)
+#else
+#define QT_STAMP(k) ((void)0)
+#define QT_COUNT(k) ((void)0)
+#endif
+
 #define QT_NOMORE 0x100
 #define QT_DEPTH(n) ((n).depthFlags & 0xff)
+// depthFlags also carries, from bit 9 up, the first bucket of the node when the keys are held as a histogram
+#define QT_B0_SHIFT 9
+#define QT_B0(n) ((int)((unsigned)(n).depthFlags >> QT_B0_SHIFT))
+#ifdef ORB_HOST_EMU
+#define QT_MFN inline
+#else
+#define QT_MFN __device__ __forceinline__
+#endif
 
-#define QT_MAX_BIN_BITS 12  // the key sort uses 2^bits buckets, bits chosen per launch (QtBins)
+#define QT_MAX_BIN_BITS 12      // the key sort uses 2^bits buckets, bits chosen per launch (QtBins)
+#define QT_MAX_BIN_BITS_BIG 14  // ... for the levels of large frames, whose workgroups take a CU's LDS for themselves
 #define QT_SMALL_BIN 40   // buckets up to this size are ordered by counting, larger ones by the bitonic network
 #ifdef ORB_HOST_EMU
 #define QT_RANK_K 64      // keys one thread holds per round of that counting (the emulation has one thread)
@@ -85,6 +111,7 @@ struct QtShared {
     unsigned best32;
     int total;
     int nL, prevSize, nToExpand, seqCounter, nRec, finish, fine, stop, err;
+    int deeper;  // histogram form only: a node with several keys would have to be divided below the bucket depth
 };
 
 // Key-sort buckets.  Once the keys are sorted the same words serve as node scratch when a level's
@@ -130,23 +157,49 @@ QT_FN void qt_work_from_pool(QtWork* w, int* pool, int nodeCap) {
 
 // Quadtree path of a key: 4 bits initial node, then ORB_CODE_DEPTH two-bit
 // quadrant digits (0 = n1 left/top, 1 = n2 right/top, 2 = n3 left/bottom,
-// 3 = n4 right/bottom), src/ORBextractor.cc:516-559, 583-602.
-QT_FN uint32_t qt_code(int x, int y, int nIni, float hX, int height) {
-    int ini = (int)QT_FDIV((float)x, hX);
+// 3 = n4 right/bottom), src/ORBextractor.cc:516-559, 583-602.  Left/right
+// choices depend on x alone (the initial node and the halving of its x range),
+// top/bottom choices on y alone, so the path is the OR of a word made from x
+// and a word made from y; the host tabulates both per level (qt_code_x over the
+// level's columns, qt_code_y over its rows) and the kernel looks them up.
+#ifdef __HIPCC__
+#define QT_HD static __host__ __device__ __forceinline__
+#else
+#define QT_HD static inline
+#endif
+#ifdef __HIP_DEVICE_COMPILE__
+#define QT_FDIV_HD(a, b) __fdiv_rn((a), (b))
+#else
+#define QT_FDIV_HD(a, b) ((a) / (b))  // IEEE division: the host is built without fast-math
+#endif
+QT_HD uint32_t qt_code_x(int x, int nIni, float hX) {
+    int ini = (int)QT_FDIV_HD((float)x, hX);
     if (ini > nIni - 1) ini = nIni - 1;  // (never taken for in-range keys; keeps the index safe)
     int x0 = (int)(hX * (float)ini), x1 = (int)(hX * (float)(ini + 1));
-    int y0 = 0, y1 = height;
     uint32_t code = (uint32_t)ini;
     for (int d = 0; d < ORB_CODE_DEPTH; d++) {
         const int halfX = (x1 - x0 + 1) >> 1;  // ceil((UR.x-UL.x)/2)
-        const int halfY = (y1 - y0 + 1) >> 1;
-        const int mx = x0 + halfX, my = y0 + halfY;
-        const int right = !(x < mx), bottom = !(y < my);
-        code = (code << 2) | (uint32_t)(bottom * 2 + right);
+        const int mx = x0 + halfX;
+        const int right = !(x < mx);
+        code = (code << 2) | (uint32_t)right;
         if (right) x0 = mx; else x1 = mx;
+    }
+    return code;
+}
+QT_HD uint32_t qt_code_y(int y, int height) {
+    int y0 = 0, y1 = height;
+    uint32_t code = 0u;
+    for (int d = 0; d < ORB_CODE_DEPTH; d++) {
+        const int halfY = (y1 - y0 + 1) >> 1;
+        const int my = y0 + halfY;
+        const int bottom = !(y < my);
+        code = (code << 2) | (uint32_t)(bottom * 2);
         if (bottom) y0 = my; else y1 = my;
     }
     return code;
+}
+QT_HD uint32_t qt_code(int x, int y, int nIni, float hX, int height) {
+    return qt_code_x(x, nIni, hX) | qt_code_y(y, height);
 }
 
 // First index in [lo, hi) whose code is >= key (codes are the high 32 bits).
@@ -286,6 +339,97 @@ QT_FN void qt_children(const unsigned long long* s, const OrbNode& nd, int* b, i
     b[2] = lo3;
 }
 
+// Bucket depth of the histogram form for a level with nIni initial nodes and quota N: the coarse passes run at
+// least until 4^d nIni >= N (depth dmin) and the fine phase goes one deeper, so dmin + 2 digits cover ordinary
+// images with a level to spare; fewer when that many buckets exceed `bucketCap` (at least one digit).
+static inline int qt_hist_depth(int nIni, int N, int bucketCap) {
+    int dmin = 0;
+    while (((long long)nIni << (2 * dmin)) < N && dmin < ORB_CODE_DEPTH) dmin++;
+    int d = dmin + 2;
+    if (d > ORB_CODE_DEPTH) d = ORB_CODE_DEPTH;
+    while (d > 1 && ((long long)nIni << (2 * d)) > bucketCap) d--;
+    return d;
+}
+
+// ---- the two forms the keys of a level are held in ------------------------------------------------------
+// A "key space" answers the three questions the distribution asks about keys: which index range an initial
+// node owns, where the children of a node begin, and which key of a node wins.  Node ranges [lo, hi) are key
+// index ranges in both forms, so everything else (list bookkeeping, sizes, orders) is shared.
+//
+// QtSortedSpace: the keys as an array sorted by (path, rank); boundaries by binary search, winner by a scan.
+struct QtSortedSpace {
+    const unsigned long long* s;
+    int n;
+    QT_MFN void ini_range(int i, int nIni, int* lo, int* hi, int* b0) const {
+        *lo = qt_lower_bound(s, 0, n, (uint32_t)i << (2 * ORB_CODE_DEPTH));
+        *hi = (i + 1 == nIni) ? n : qt_lower_bound(s, *lo, n, (uint32_t)(i + 1) << (2 * ORB_CODE_DEPTH));
+        *b0 = 0;
+    }
+    QT_MFN void children(const OrbNode& nd, int* b, int* err, int* deeper) const {
+        (void)deeper;
+        qt_children(s, nd, b, err);
+    }
+    QT_MFN int child_b0(const OrbNode&, int) const { return 0; }
+    QT_MFN int items(const OrbNode& nd) const { return nd.hi - nd.lo; }
+    QT_MFN uint32_t prio_at(const OrbNode& nd, int i) const { return qt_entry_prio(s[nd.lo + i]); }
+};
+
+// QtHistSpace: no key array at all.  The keys are counted into buckets = quadtree cells of depth Db (bucket number
+// = the first 4 + 2 Db bits of the path), start[] is the prefix sum of the counts and best[] the largest priority
+// word (response << 24 | ~rank) per bucket.  A node of depth d <= Db is a run of 4^(Db - d) buckets: its children
+// begin at three entries of start[], its winner is the largest entry of best[] over the run.  Below the bucket
+// depth only nodes with a single key can be followed (the key's own path says which child it falls into; the
+// fork's rule divides such nodes over and over); a node with several keys there sets *deeper and the caller
+// runs the level again in the sorted form.  RankCode maps a key's rank to its path.
+template <class RankCode>
+struct QtHistSpace {
+    const int* start;      // nb + 1
+    const uint32_t* best;  // nb
+    int Db;
+    RankCode codeOf;
+    QT_MFN void ini_range(int i, int nIni, int* lo, int* hi, int* b0) const {
+        (void)nIni;
+        const int span = 1 << (2 * Db);
+        *b0 = i * span;
+        *lo = start[i * span];
+        *hi = start[(i + 1) * span];
+    }
+    QT_MFN void children(const OrbNode& nd, int* b, int* err, int* deeper) const {
+        const int d = QT_DEPTH(nd), b0 = QT_B0(nd);
+        if (d >= ORB_CODE_DEPTH) {
+            *err = 1;
+            b[0] = b[1] = b[2] = nd.hi;
+            return;
+        }
+        if (d < Db) {
+            const int span = 1 << (2 * (Db - d - 1));
+            b[0] = start[b0 + span];
+            b[1] = start[b0 + 2 * span];
+            b[2] = start[b0 + 3 * span];
+            return;
+        }
+        if (nd.hi - nd.lo != 1) {
+            *deeper = 1;
+            b[0] = b[1] = b[2] = nd.hi;
+            return;
+        }
+        const uint32_t code = codeOf(~best[b0] & 0xffffffu);
+        const int q = (int)((code >> (2 * (ORB_CODE_DEPTH - 1 - d))) & 3u);
+        b[0] = q >= 1 ? nd.lo : nd.hi;
+        b[1] = q >= 2 ? nd.lo : nd.hi;
+        b[2] = q >= 3 ? nd.lo : nd.hi;
+    }
+    QT_MFN int child_b0(const OrbNode& nd, int q) const {
+        const int d = QT_DEPTH(nd);
+        return d < Db ? QT_B0(nd) + q * (1 << (2 * (Db - d - 1))) : QT_B0(nd);
+    }
+    QT_MFN int items(const OrbNode& nd) const {
+        const int d = QT_DEPTH(nd);
+        return d < Db ? 1 << (2 * (Db - d)) : 1;
+    }
+    QT_MFN uint32_t prio_at(const OrbNode& nd, int i) const { return best[QT_B0(nd) + i]; }  // 0: empty bucket
+};
+
 QT_FN int qt_child_flags(int q, int cnt, int n3quirk) {
     // src/ORBextractor.cc:561-568: one-key children stop; with the fork's stray
     // ';' n3 always stops and n4 never does.
@@ -299,8 +443,9 @@ QT_FN int qt_child_flags(int q, int cnt, int n3quirk) {
 // Writes the children of `nd` (boundaries b) in list order n4,n3,n2,n1 starting
 // at dst[pos]; creation numbers run n1..n4 from seq0.  Children with more than
 // one key are recorded at rec[recPos..].
-QT_FN void qt_emit_children(const OrbNode& nd, const int* b, OrbNode* dst, int pos, int seq0, int* rec, int recPos,
-                            int n3quirk) {
+template <class Space>
+QT_FN void qt_emit_children(const Space& sp, const OrbNode& nd, const int* b, OrbNode* dst, int pos, int seq0, int* rec,
+                            int recPos, int n3quirk) {
     const int lo[4] = {nd.lo, b[0], b[1], b[2]};
     const int hi[4] = {b[0], b[1], b[2], nd.hi};
     int seqs[4], s = seq0;
@@ -312,7 +457,7 @@ QT_FN void qt_emit_children(const OrbNode& nd, const int* b, OrbNode* dst, int p
         OrbNode c;
         c.lo = lo[q];
         c.hi = hi[q];
-        c.depthFlags = d | qt_child_flags(q, cnt, n3quirk);
+        c.depthFlags = d | qt_child_flags(q, cnt, n3quirk) | (sp.child_b0(nd, q) << QT_B0_SHIFT);
         c.seq = seqs[q];
         dst[pos] = c;
         pos++;
@@ -329,12 +474,12 @@ QT_FN void qt_emit_children(const OrbNode& nd, const int* b, OrbNode* dst, int p
     }
 }
 
-// Runs the distribution.  `sorted` holds n (code, rank) entries in ascending
-// order.  On return *outCount nodes are in `*outList` in list order.
-QT_FN void qt_distribute(const QtWork& w, int n, int nIni, int N, int n3quirk, QtShared* sh, OrbNode** outList,
+// Runs the distribution over the keys of `sp`.  On return *outCount nodes are in `*outList` in list order;
+// sh->deeper != 0 means the histogram form could not follow the reference any further (the list is then void).
+template <class Space>
+QT_FN void qt_distribute(const Space& sp, const QtWork& w, int nIni, int N, int n3quirk, QtShared* sh, OrbNode** outList,
                          int* outCount) {
     const int T = QT_NT, t = QT_TID;
-    const unsigned long long* s = w.sorted;
     OrbNode* cur = w.listA;
     OrbNode* nxt = w.listB;
 
@@ -342,13 +487,13 @@ QT_FN void qt_distribute(const QtWork& w, int n, int nIni, int N, int n3quirk, Q
     if (t == 0) {
         int nL = 0;
         for (int i = 0; i < nIni; i++) {
-            const int lo = qt_lower_bound(s, 0, n, (uint32_t)i << (2 * ORB_CODE_DEPTH));
-            const int hi = (i + 1 == nIni) ? n : qt_lower_bound(s, lo, n, (uint32_t)(i + 1) << (2 * ORB_CODE_DEPTH));
+            int lo, hi, b0;
+            sp.ini_range(i, nIni, &lo, &hi, &b0);
             if (hi == lo) continue;
             OrbNode nd;
             nd.lo = lo;
             nd.hi = hi;
-            nd.depthFlags = (hi - lo == 1) ? QT_NOMORE : 0;
+            nd.depthFlags = ((hi - lo == 1) ? QT_NOMORE : 0) | (b0 << QT_B0_SHIFT);
             nd.seq = i;
             cur[nL++] = nd;
         }
@@ -356,20 +501,26 @@ QT_FN void qt_distribute(const QtWork& w, int n, int nIni, int N, int n3quirk, Q
         sh->seqCounter = nIni;
         sh->finish = 0;
         sh->err = 0;
+        sh->deeper = 0;
     }
     QT_BARRIER();
 
     while (!sh->finish) {
         // ---- coarse pass, src/ORBextractor.cc:625-697 ------------------------------
+        QT_COUNT(16);
+#if defined(QT_PROFILE) && !defined(ORB_HOST_EMU)
+        if (blockIdx.x == 0 && threadIdx.x == 0 && g_qtProfile[16] < 6) g_qtProfile[19 + g_qtProfile[16]] = wall_clock64();
+#endif
         const int nL = sh->nL;
         for (int i = t; i < nL; i += T) {
             const OrbNode nd = cur[i];
             int k = 0, e = 0, nm = 1;
             if (!(nd.depthFlags & QT_NOMORE)) {
                 int b[3];
-                int err = 0;
-                qt_children(s, nd, b, &err);
+                int err = 0, deeper = 0;
+                sp.children(nd, b, &err, &deeper);
                 if (err) sh->err = 1;
+                if (deeper) sh->deeper = 1;
                 w.bounds[4 * i + 0] = b[0];
                 w.bounds[4 * i + 1] = b[1];
                 w.bounds[4 * i + 2] = b[2];
@@ -383,6 +534,7 @@ QT_FN void qt_distribute(const QtWork& w, int n, int nIni, int N, int n3quirk, Q
             w.scanC[i] = nm;
         }
         QT_BARRIER();
+        if (sh->deeper) break;  // (same for every thread: written before the barrier)
         qt_scan3(w.scanA, w.scanB, w.scanC, nL, sh);
         const int totalChildren = w.scanA[nL], nToExpand = w.scanB[nL], nStay = w.scanC[nL];
         if (totalChildren + nStay > w.nodeCap) {  // cannot happen by the size bound; fail loudly
@@ -398,7 +550,7 @@ QT_FN void qt_distribute(const QtWork& w, int n, int nIni, int N, int n3quirk, Q
             } else {
                 const int k = w.scanA[i + 1] - w.scanA[i];
                 const int pos = totalChildren - w.scanA[i] - k;  // blocks of later nodes come first
-                qt_emit_children(nd, &w.bounds[4 * i], nxt, pos, seq0 + w.scanA[i], w.rec, w.scanB[i], n3quirk);
+                qt_emit_children(sp, nd, &w.bounds[4 * i], nxt, pos, seq0 + w.scanA[i], w.rec, w.scanB[i], n3quirk);
             }
         }
         QT_BARRIER();
@@ -417,31 +569,48 @@ QT_FN void qt_distribute(const QtWork& w, int n, int nIni, int N, int n3quirk, Q
 
         // ---- fine phase, src/ORBextractor.cc:702-770 ------------------------------
         while (sh->fine && !sh->finish) {
+            QT_COUNT(17);
+#if defined(QT_PROFILE) && !defined(ORB_HOST_EMU)
+            if (blockIdx.x == 0 && threadIdx.x == 0 && g_qtProfile[17] < 4) {
+                g_qtProfile[25 + g_qtProfile[17]] = wall_clock64();
+                g_qtProfile[11] = (unsigned long long)sh->nRec;
+                g_qtProfile[12] = (unsigned long long)sh->nL;
+            }
+#endif
             const int nLf = sh->nL, nR = sh->nRec;
-            // order recorded nodes by (size, creation number) descending: sizes and creation numbers are
-            // first laid out densely, so that the counting loop reads two words per step and nothing else
+            // order recorded nodes by (size, creation number) descending: both are first laid out densely as one
+            // 64-bit word per node (in `bounds`, which is free until the children are computed), so that the
+            // counting loop reads one word per step and nothing else; words are unique (creation numbers are)
+            unsigned long long* const ordKey = (unsigned long long*)w.bounds;  // nodeCap * 4 ints = 2 nodeCap words
             for (int j = t; j < nR; j += T) {
                 const OrbNode a = cur[w.rec[j]];
-                w.scanA[j] = a.hi - a.lo;
-                w.scanB[j] = a.seq;
+                ordKey[j] = ((unsigned long long)(unsigned)(a.hi - a.lo) << 32) | (unsigned)a.seq;
             }
             QT_BARRIER();
             for (int j = t; j < nR; j += T) {
-                const int sa = w.scanA[j], qa = w.scanB[j];
+                const unsigned long long mine = ordKey[j];
                 int r = 0;
-                for (int m = 0; m < nR; m++) {
-                    const int sc = w.scanA[m], qc = w.scanB[m];
-                    r += (sc > sa) || (sc == sa && qc > qa);
+                int m = 0;
+#ifndef ORB_HOST_EMU
+                for (; m + 8 <= nR; m += 8) {  // eight independent loads per step
+                    unsigned long long o[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) o[u] = ordKey[m + u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) r += o[u] > mine;
                 }
+#endif
+                for (; m < nR; m++) r += ordKey[m] > mine;
                 w.recSorted[r] = w.rec[j];
             }
             QT_BARRIER();
             for (int j = t; j < nR; j += T) {
                 const OrbNode nd = cur[w.recSorted[j]];
                 int b[3];
-                int err = 0;
-                qt_children(s, nd, b, &err);
+                int err = 0, deeper = 0;
+                sp.children(nd, b, &err, &deeper);
                 if (err) sh->err = 1;
+                if (deeper) sh->deeper = 1;
                 w.bounds[4 * j + 0] = b[0];
                 w.bounds[4 * j + 1] = b[1];
                 w.bounds[4 * j + 2] = b[2];
@@ -451,6 +620,7 @@ QT_FN void qt_distribute(const QtWork& w, int n, int nIni, int N, int n3quirk, Q
             }
             if (t == 0) sh->stop = nR - 1;
             QT_BARRIER();
+            if (sh->deeper) break;
             qt_scan3(w.scanA, w.scanB, nullptr, nR, sh);
             // the list reaches the quota after processing node j when nLf + (children - parents) >= N
             for (int j = t; j < nR; j += T) {
@@ -480,7 +650,7 @@ QT_FN void qt_distribute(const QtWork& w, int n, int nIni, int N, int n3quirk, Q
                 const OrbNode nd = cur[w.recSorted[j]];
                 const int k = w.scanA[j + 1] - w.scanA[j];
                 const int pos = childrenProc - w.scanA[j] - k;
-                qt_emit_children(nd, &w.bounds[4 * j], nxt, pos, seqF + w.scanA[j], w.rec, w.scanB[j], n3quirk);
+                qt_emit_children(sp, nd, &w.bounds[4 * j], nxt, pos, seqF + w.scanA[j], w.rec, w.scanB[j], n3quirk);
             }
             QT_BARRIER();
             if (t == 0) {
@@ -493,9 +663,10 @@ QT_FN void qt_distribute(const QtWork& w, int n, int nIni, int N, int n3quirk, Q
             { OrbNode* tmp = cur; cur = nxt; nxt = tmp; }
             QT_BARRIER();
         }
+        if (sh->deeper) break;
     }
     *outList = cur;
-    *outCount = sh->nL;
+    *outCount = sh->deeper ? 0 : sh->nL;
 }
 
 // In-place ascending sort of a[0..n) by the whole 64-bit value: bitonic network
@@ -532,19 +703,16 @@ QT_FN void qt_sort(unsigned long long* a, int n) {
     }
 }
 
-// Winner of a node: rank of the entry with the largest priority.
-QT_FN int qt_select(const unsigned long long* sorted, const OrbNode& nd) {
-    unsigned long long best = sorted[nd.lo];
-    uint32_t bestPrio = qt_entry_prio(best);
-    for (int i = nd.lo + 1; i < nd.hi; i++) {
-        const unsigned long long e = sorted[i];
-        const uint32_t pr = qt_entry_prio(e);
-        if (pr > bestPrio) {
-            bestPrio = pr;
-            best = e;
-        }
+// Winner of a node: rank of the key with the largest priority word (priorities are unique: they hold the rank).
+template <class Space>
+QT_FN int qt_select(const Space& sp, const OrbNode& nd) {
+    const int m = sp.items(nd);
+    uint32_t best = sp.prio_at(nd, 0);
+    for (int i = 1; i < m; i++) {
+        const uint32_t pr = sp.prio_at(nd, i);
+        if (pr > best) best = pr;
     }
-    return (int)qt_entry_rank(best);
+    return (int)(~best & 0xffffffu);
 }
 
 // Sorts the n entries of `tmp` into `sorted`, ascending.
@@ -581,6 +749,7 @@ QT_FN void qt_sort_keys(const unsigned long long* tmp, unsigned long long* sorte
         sorted[pos] = e;
     }
     QT_BARRIER();
+    QT_STAMP(2);
     // Order inside the buckets.  Buckets of up to QT_SMALL_BIN entries: every key counts the entries of its
     // bucket that are smaller (entries are unique, so that count is its place), all keys at once, holds
     // itself in a register across a barrier and moves.  The keys are taken in rounds of QT_RANK_K per
@@ -627,7 +796,9 @@ QT_FN void qt_sort_keys(const unsigned long long* tmp, unsigned long long* sorte
         base = end;
     }
     const int nBig = sh->nBig;
+    QT_STAMP(3);
     for (int k = 0; k < nBig; k++) {
+        QT_COUNT(18);
         const int b = binCursor[k];
         const int lo = binStart[b];
         qt_sort(sorted + lo, binStart[b + 1] - lo);
@@ -635,39 +806,32 @@ QT_FN void qt_sort_keys(const unsigned long long* tmp, unsigned long long* sorte
 }
 
 // Winners of all `count` nodes of the final list: outRank[i] = rank of node i's
-// winner.  Nodes with few keys are handled by one thread each; a node that
-// still holds many keys (with the fork's n3 rule whole quadrants are never
-// divided) is scanned by the whole workgroup and reduced with one LDS atomic
-// max on the priority word; the rank is the complement of its low 24 bits.
+// winner.  Nodes with few items (keys, or buckets in the histogram form) are handled by one thread each; a
+// node that still holds many (with the fork's n3 rule whole quadrants are never divided) is scanned by a whole
+// wavefront.
 #define QT_SELECT_SERIAL 64
-QT_FN void qt_select_all(const unsigned long long* sorted, const OrbNode* list, int count, int* outRank,
-                         QtShared* sh) {
+template <class Space>
+QT_FN void qt_select_all(const Space& sp, const OrbNode* list, int count, int* outRank, QtShared* sh) {
     const int T = QT_NT, t = QT_TID;
     if (t == 0) sh->nBig = 0;
     QT_BARRIER();
     for (int i = t; i < count; i += T) {
         const OrbNode nd = list[i];
-        if (nd.hi - nd.lo > QT_SELECT_SERIAL) {
+        if (sp.items(nd) > QT_SELECT_SERIAL) {
             const int k = QT_ATOMIC_ADD(&sh->nBig, 1);
             if (k < QT_BIG_LIST) {  // (more large nodes than list slots: the rest stay with their thread)
                 sh->bigList[k] = i;
                 continue;
             }
         }
-        outRank[i] = qt_select(sorted, nd);
+        outRank[i] = qt_select(sp, nd);
     }
     QT_BARRIER();
     const int nBig = sh->nBig < QT_BIG_LIST ? sh->nBig : QT_BIG_LIST;
 #ifdef ORB_HOST_EMU
     for (int k = 0; k < nBig; k++) {
         const int i = sh->bigList[k];
-        const OrbNode nd = list[i];
-        uint32_t best = 0u;
-        for (int p = nd.lo; p < nd.hi; p++) {
-            const uint32_t pr = qt_entry_prio(sorted[p]);
-            if (pr > best) best = pr;
-        }
-        outRank[i] = (int)(~best & 0xffffffu);
+        outRank[i] = qt_select(sp, list[i]);
     }
 #else
     // one wavefront per large node, the wavefronts of the workgroup working on different nodes at once
@@ -675,9 +839,10 @@ QT_FN void qt_select_all(const unsigned long long* sorted, const OrbNode* list, 
     for (int k = wv; k < nBig; k += nw) {
         const int i = sh->bigList[k];
         const OrbNode nd = list[i];
+        const int m = sp.items(nd);
         uint32_t best = 0u;
-        for (int p = nd.lo + lane; p < nd.hi; p += 64) {
-            const uint32_t pr = qt_entry_prio(sorted[p]);
+        for (int p = lane; p < m; p += 64) {
+            const uint32_t pr = sp.prio_at(nd, p);
             if (pr > best) best = pr;
         }
 #pragma unroll

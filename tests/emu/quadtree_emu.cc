@@ -27,12 +27,56 @@ extern "C" int qt_emu_distribute(const int* xs, const int* ys, const int* scores
     QtWork w;
     qt_work_from_pool(&w, pool.data(), nodeCap);
     w.sorted = sorted.data();
+    const QtSortedSpace sp = {sorted.data(), n};
     OrbNode* out = nullptr;
     int cnt = 0;
-    if (n > 0) qt_distribute(w, n, nIni, N, n3quirk, &sh, &out, &cnt);
+    if (n > 0) qt_distribute(sp, w, nIni, N, n3quirk, &sh, &out, &cnt);
     *err = n > 0 ? sh.err : 0;
     std::vector<int> ranks(cnt > 0 ? cnt : 1);
-    if (cnt > 0) qt_select_all(sorted.data(), out, cnt, ranks.data(), &sh);
+    if (cnt > 0) qt_select_all(sp, out, cnt, ranks.data(), &sh);
     for (int i = 0; i < cnt && i < outCap; i++) outRank[i] = (ranks[i] - 1) / 3;
     return cnt;
 }
+
+// The histogram form of the same distribution (no key array: per-bucket counts and best priorities, buckets =
+// quadtree cells of depth Db).  Returns the node count, or -1 when a node with several keys would have to be
+// divided below the bucket depth (the device then runs the level again in the sorted form).
+struct EmuRankCode {
+    const uint32_t* codes;  // by key index
+    uint32_t operator()(uint32_t rank) const { return codes[(rank - 1) / 3]; }
+};
+extern "C" int qt_emu_distribute_hist(const int* xs, const int* ys, const int* scores, int n, int nIni, float hX, int height,
+                                      int N, int n3quirk, int Db, int* outRank, int outCap, int* err) {
+    static QtShared sh;
+    const int nb = nIni << (2 * Db);
+    std::vector<int> start((std::size_t)nb + 1, 0);
+    std::vector<uint32_t> best((std::size_t)nb, 0u), codes(n > 0 ? n : 1);
+    for (int i = 0; i < n; i++) {
+        codes[i] = qt_code(xs[i], ys[i], nIni, hX, height);
+        const uint32_t b = codes[i] >> (2 * (ORB_CODE_DEPTH - Db));
+        const uint32_t prio = qt_entry_prio(qt_entry(codes[i], (uint32_t)(3 * i + 1), (uint32_t)scores[i]));
+        start[b]++;
+        if (prio > best[b]) best[b] = prio;
+    }
+    qt_scan(start.data(), nb, &sh);
+    if (start[nb] != n) return -200;
+    const int nodeCap = (N + 3 > 4 * nIni ? N + 3 : 4 * nIni) + 8;
+    std::vector<int> pool((std::size_t)QT_NODE_INTS(nodeCap));
+    QtWork w;
+    qt_work_from_pool(&w, pool.data(), nodeCap);
+    w.sorted = nullptr;
+    const QtHistSpace<EmuRankCode> sp = {start.data(), best.data(), Db, {codes.data()}};
+    OrbNode* out = nullptr;
+    int cnt = 0;
+    if (n > 0) qt_distribute(sp, w, nIni, N, n3quirk, &sh, &out, &cnt);
+    *err = n > 0 ? sh.err : 0;
+    if (n > 0 && sh.deeper) return -1;
+    std::vector<int> ranks(cnt > 0 ? cnt : 1);
+    if (cnt > 0) qt_select_all(sp, out, cnt, ranks.data(), &sh);
+    for (int i = 0; i < cnt && i < outCap; i++) outRank[i] = (ranks[i] - 1) / 3;
+    return cnt;
+}
+
+// Bucket depth the device uses for a level: two digits below the depth at which the initial nodes' descendants
+// can first reach the quota, as far as `bucketCap` buckets allow (orb_api.hip computes the same).
+extern "C" int qt_emu_hist_depth(int nIni, int N, int bucketCap) { return qt_hist_depth(nIni, N, bucketCap); }

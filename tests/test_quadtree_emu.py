@@ -39,6 +39,31 @@ def run_emu(emu, keys, min_x, max_x, min_y, max_y, N, n3quirk):
     return out[:cnt]
 
 
+HIST = {"runs": 0, "deeper": 0}
+
+
+def run_emu_hist(emu, keys, min_x, max_x, min_y, max_y, N, n3quirk, bucket_cap):
+    """The histogram form; None when it reports that the level needs the sorted form."""
+    xs = np.ascontiguousarray(keys["x"], dtype=np.int32)
+    ys = np.ascontiguousarray(keys["y"], dtype=np.int32)
+    sc = np.ascontiguousarray(keys["response"], dtype=np.int32)
+    w, h = max_x - min_x, max_y - min_y
+    n_ini = int(math.floor(np.float32(w) / np.float32(h) + np.float32(0.5)))
+    hx = np.float32(w) / np.float32(n_ini)
+    out = np.zeros(len(keys) + 16, dtype=np.int32)
+    err = C.c_int(0)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    db = emu.qt_emu_hist_depth(n_ini, N, bucket_cap)
+    cnt = emu.qt_emu_distribute_hist(p(xs), p(ys), p(sc), len(keys), n_ini, C.c_float(hx), h, N, int(n3quirk), db, p(out),
+                                     len(out), C.byref(err))
+    assert cnt >= -1 and err.value == 0
+    HIST["runs"] += 1
+    if cnt == -1:
+        HIST["deeper"] += 1
+        return None
+    return out[:cnt]
+
+
 def check(emu, oracle, e, keys, min_x, max_x, min_y, max_y, N, quirk):
     ref = e.distribute(keys, min_x, max_x, min_y, max_y, N)
     got = run_emu(emu, keys, min_x, max_x, min_y, max_y, N, quirk)
@@ -46,6 +71,11 @@ def check(emu, oracle, e, keys, min_x, max_x, min_y, max_y, N, quirk):
     np.testing.assert_array_equal(keys["x"][got], ref["x"])
     np.testing.assert_array_equal(keys["y"][got], ref["y"])
     np.testing.assert_array_equal(keys["response"][got], ref["response"])
+    # the histogram form either gives the same list or asks for the sorted form
+    for cap in (4096, 64):
+        h = run_emu_hist(emu, keys, min_x, max_x, min_y, max_y, N, quirk, cap)
+        if h is not None:
+            np.testing.assert_array_equal(h, got, err_msg="histogram form, %d buckets at most" % cap)
 
 
 @pytest.mark.parametrize("quirk", [True, False])
@@ -61,6 +91,10 @@ def test_emu_matches_oracle_on_fast_keys(emu, oracle, quirk):
                 keys = e.level_keys(l, after_quadtree=False)
                 lw, lh = e.level(l).shape[::-1]
                 check(emu, oracle, e, keys, 16, lw - 16, 16, lh - 16, int(per[l]), quirk)
+                before = dict(HIST)
+                check(emu, oracle, e, keys, 16, lw - 16, 16, lh - 16, int(per[l]), quirk)
+                # at the level's own quota and 4096 buckets the histogram form must do (it is the fast path)
+                assert HIST["deeper"] - before["deeper"] <= 1, "level %d of %dx%d fell back to the sorted form" % (l, w, h)
                 # other quotas exercise early termination, the fine phase and exhaustion
                 for N in (1, 7, 50, len(keys) // 2, len(keys) + 10):
                     check(emu, oracle, e, keys, 16, lw - 16, 16, lh - 16, max(1, N), quirk)
@@ -97,3 +131,4 @@ def test_emu_matches_oracle_on_random_keys(emu, oracle, quirk):
         emu.qt_emu_set_bin_bits([12, 11, 10, 6, 1][trial % 5])  # bucket counts a launch may choose, and tiny ones
         check(emu, oracle, e, keys, 16, 16 + w, 16, 16 + h, N, quirk)
     emu.qt_emu_set_bin_bits(12)
+    assert 0 < HIST["deeper"] < HIST["runs"]  # both outcomes of the histogram form occurred
