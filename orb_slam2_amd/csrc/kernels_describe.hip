@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
                                                              const int* __restrict__ levelCount,
                                                              orb_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                              int capPerFrame, int* __restrict__ nOut,
-                                                             int* __restrict__ error) {
+                                                             int* __restrict__ error, int* __restrict__ status) {
     __shared__ __attribute__((aligned(16))) uint8_t s_raw[DESC_WAVES][(RAW_N + 1) * RAW_P];  // + the partner row of row 42
     __shared__ __attribute__((aligned(16))) uint32_t s_hb[DESC_WAVES][HB_PAIRS * HB_P];
     // the wavefront index is the same in all 64 lanes: telling the compiler so keeps everything derived from
@@ -191,6 +191,9 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     if (slot == 0 && lane == 0) {
         nOut[frame] = total;
         if (total > capPerFrame) atomicOr(error, 64);  // caller's buffers too small: reported, rows beyond cap dropped
+        // Callers that read their results without a copy of the error word get it per frame: everything the earlier
+        // stages flagged (they are complete) and this frame's own overflow.
+        if (status) status[frame] = __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (total > capPerFrame ? 64 : 0);
     }
     if (i >= lc[level]) return;
     const int outIdx = before + i;
@@ -423,7 +426,7 @@ int orb_launch_describe(const OrbBatch& b) {
     const int64_t blocks = orb_xcd_grid(b.nframes, g.outCapFrame);
     hipLaunchKernelGGL(k_describe, dim3((unsigned)blocks), dim3(64 * DESC_WAVES), 0, (hipStream_t)b.stream, b.d_geom,
                        b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, b.nframes, b.d_selXY, b.d_selScore,
-                       b.d_levelCount, b.d_kps, b.d_desc, b.capPerFrame, b.d_nOut, b.d_error);
+                       b.d_levelCount, b.d_kps, b.d_desc, b.capPerFrame, b.d_nOut, b.d_error, b.d_status);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         orb_set_error("describe launch failed: %s", hipGetErrorString(e));

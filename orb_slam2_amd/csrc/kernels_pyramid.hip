@@ -337,10 +337,129 @@ static int launch_resize(bool area, int ntaps, const uint8_t* src, int sw, int s
     return check_launch("resize");
 }
 
+// Few frames (the reference's one frame per call): seven dependent launches of a few microseconds each cost more in
+// launch gaps than in work.  Here one launch builds every level.  The frame is cut into a grid of tiles, the same
+// grid at every level; a workgroup reads the part of level 0 its tile depends on into LDS and resizes it level
+// by level from one LDS buffer into the other, recomputing the pixels near its borders that its neighbours also
+// compute (identical arithmetic, identical values) instead of waiting for them, and stores the pixels it owns.
+// The regions come from the tap tables (OrbGeom::chainX / chainY, built on the host).  Per pixel the arithmetic is
+// that of k_resize_tiled: same products, same sums, same order.
+#define PF_THREADS 1024
+#define PF_COLS 128  // threads along x; the eight wavefront pairs of a workgroup take rows in turn
+template <bool AREA>
+__global__ __launch_bounds__(PF_THREADS) void k_pyramid_few(const OrbGeom* __restrict__ g, const uint8_t* __restrict__ img0,
+                                                            int stride0, int64_t frameStride0, uint8_t* __restrict__ pyr,
+                                                            int frame0, const void* __restrict__ taps, int bufBytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
+    const int GX = g->chainGX, tiles = GX * g->chainGY;
+    const int frameLocal = (int)blockIdx.x / tiles, tile = (int)blockIdx.x - frameLocal * tiles;
+    const int tj = tile / GX, ti = tile - tj * GX;
+    const int frame = frame0 + frameLocal;
+    const int t = threadIdx.x, lx = t & (PF_COLS - 1);
+    const int ly = __builtin_amdgcn_readfirstlane(t / PF_COLS);  // the same in all lanes of a wavefront
+    constexpr int LY = PF_THREADS / PF_COLS;
+    uint8_t* cur = s_mem;
+    uint8_t* nxt = s_mem + bufBytes;
+
+    // level 0: the region's rows as dwords (its first column is a multiple of 4)
+    int rx0 = g->chainX[0][ti][0], rx1 = g->chainX[0][ti][1], ry0 = g->chainY[0][tj][0], ry1 = g->chainY[0][tj][1];
+    int pitch = ((rx1 - rx0) + 3) & ~3;
+    {
+        const uint8_t* S = img0 + (int64_t)frame * frameStride0;
+        const int w0 = g->lv[0].w;
+        const bool aligned = (stride0 & 3) == 0 && (((unsigned long long)S) & 3ull) == 0;
+        const int nd = pitch >> 2, col = rx0 + 4 * lx;
+        if (lx < nd)
+            for (int r = ly; r < ry1 - ry0; r += LY) {
+                const uint8_t* p = S + (int64_t)(ry0 + r) * stride0 + col;
+                uint32_t v = 0u;
+                if (aligned && col + 3 < w0) {
+                    v = *(const uint32_t*)p;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (col + i < w0) v |= (uint32_t)p[i] << (8 * i);
+                }
+                *(uint32_t*)&cur[r * pitch + 4 * lx] = v;
+            }
+    }
+    __syncthreads();
+
+    for (int k = 1; k < g->nlevels; k++) {
+        const OrbLevel& L = g->lv[k];
+        const int dx0 = g->chainX[k][ti][0], dx1 = g->chainX[k][ti][1], ox0 = g->chainX[k][ti][2], ox1 = g->chainX[k][ti][3];
+        const int dy0 = g->chainY[k][tj][0], dy1 = g->chainY[k][tj][1], oy0 = g->chainY[k][tj][2], oy1 = g->chainY[k][tj][3];
+        const int dpitch = ((dx1 - dx0) + 3) & ~3;
+        uint8_t* D = pyr + L.off + (int64_t)frame * L.frameStride;
+        for (int x = dx0 + lx; x < dx1; x += PF_COLS) {
+            const bool ownX = x >= ox0 && x < ox1;
+            if (AREA) {
+                const OrbAreaTap tx = ((const OrbAreaTap*)taps)[L.tabX + x];
+                // the taps of a column are consecutive source pixels from si[0] on: the two aligned dwords that
+                // hold them, shifted; unused taps have weight 0 (buf + pixel * 0 == buf), whatever lies under them
+                const int b0 = tx.si[0] - rx0, sh = b0 & 3;
+                const uint32_t* rowp = (const uint32_t*)cur + (b0 >> 2);
+                const int rowStep = pitch >> 2;
+                for (int y = dy0 + ly; y < dy1; y += LY) {
+                    const OrbAreaTap ty = ((const OrbAreaTap*)taps)[L.tabY + y];
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < ORB_MAX_TAPS; j++) {
+                        const uint32_t* p = rowp + (ty.si[j] - ry0) * rowStep;
+                        const uint32_t w = __builtin_amdgcn_alignbyte(p[1], p[0], sh);
+                        float buf = (float)(w & 255u) * tx.a[0];
+                        buf = buf + (float)((w >> 8) & 255u) * tx.a[1];
+                        buf = buf + (float)((w >> 16) & 255u) * tx.a[2];
+                        buf = buf + (float)(w >> 24) * tx.a[3];
+                        s = (j == 0) ? buf * ty.a[0] : s + buf * ty.a[j];
+                    }
+                    const uint8_t v = (uint8_t)(__builtin_amdgcn_cvt_pk_u8_f32(s, 0u, 0u) & 255u);  // saturate_cast<uchar>
+                    nxt[(y - dy0) * dpitch + (x - dx0)] = v;
+                    if (ownX && y >= oy0 && y < oy1) D[(int64_t)y * L.pitch + x] = v;
+                }
+            } else {
+                const OrbLinTap tx = ((const OrbLinTap*)taps)[L.tabX + x];
+                const uint8_t* c0 = cur + (tx.s0 - rx0);
+                const uint8_t* c1 = cur + (tx.s1 - rx0);
+                for (int y = dy0 + ly; y < dy1; y += LY) {
+                    const OrbLinTap ty = ((const OrbLinTap*)taps)[L.tabY + y];
+                    const int r0 = (ty.s0 - ry0) * pitch, r1 = (ty.s1 - ry0) * pitch;
+                    const int H0 = c0[r0] * tx.a0 + c1[r0] * tx.a1, H1 = c0[r1] * tx.a0 + c1[r1] * tx.a1;
+                    const uint8_t v = (uint8_t)(((((ty.a0 * (H0 >> 4)) >> 16) + ((ty.a1 * (H1 >> 4)) >> 16) + 2) >> 2) & 255);
+                    nxt[(y - dy0) * dpitch + (x - dx0)] = v;
+                    if (ownX && y >= oy0 && y < oy1) D[(int64_t)y * L.pitch + x] = v;
+                }
+            }
+        }
+        __syncthreads();
+        uint8_t* sw = cur;
+        cur = nxt;
+        nxt = sw;
+        rx0 = dx0;
+        ry0 = dy0;
+        pitch = dpitch;
+    }
+}
+
+static int launch_pyramid_few(const OrbBatch& b) {
+    const OrbGeom& g = *b.h_geom;
+    const bool area = (g.quirks & ORB_Q_RESIZE_AREA) != 0;
+    const int bufBytes = g.chainLds / 2;
+    const dim3 grid((unsigned)(b.nframes * g.chainGX * g.chainGY));
+    if (area)
+        hipLaunchKernelGGL(k_pyramid_few<true>, grid, dim3(PF_THREADS), (size_t)g.chainLds, (hipStream_t)b.stream, b.d_geom,
+                           b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, (const void*)b.d_areaTaps, bufBytes);
+    else
+        hipLaunchKernelGGL(k_pyramid_few<false>, grid, dim3(PF_THREADS), (size_t)g.chainLds, (hipStream_t)b.stream, b.d_geom,
+                           b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, (const void*)b.d_linTaps, bufBytes);
+    return check_launch("pyramid");
+}
+
 int orb_launch_pyramid(const OrbBatch& b) {
     const OrbGeom& g = *b.h_geom;
     hipStream_t st = (hipStream_t)b.stream;
     const bool area = (g.quirks & ORB_Q_RESIZE_AREA) != 0;
+    if (b.nframes < ORB_FEW_FRAMES && g.chainGX > 0 && g.nlevels > 1) return launch_pyramid_few(b);
     for (int l = 1; l < g.nlevels; l++) {
         const OrbLevel& D = g.lv[l];
         const OrbLevel& P = g.lv[l - 1];

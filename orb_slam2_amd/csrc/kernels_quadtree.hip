@@ -215,10 +215,7 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __re
         QT_STAMP(1);
         qt_scan(start, nb, &sh);
         const int n = start[nb];
-        if (t == 0) {
-            levelKeys[frame * nlevels + level] = n;
-            if (n > error[1]) atomicMax(&error[1], n);
-        }
+        if (t == 0) levelKeys[frame * nlevels + level] = n;
         if (n > L.keyCap) {  // cannot happen: keyCap is the 2x2-block bound summed over the cells
             if (t == 0) {
                 atomicOr(error, 4);
@@ -287,10 +284,7 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __re
         n += chunk;
         __syncthreads();
     }
-    if (t == 0) {
-        levelKeys[frame * nlevels + level] = n;
-        if (n > error[1]) atomicMax(&error[1], n);
-    }
+    if (t == 0) levelKeys[frame * nlevels + level] = n;
     if (n > L.keyCap) {  // cannot happen: keyCap is the 2x2-block bound summed over the cells
         if (t == 0) {
             atomicOr(error, 4);

@@ -108,16 +108,14 @@ struct orb_ctx {
     hipEvent_t evFork = nullptr, evJoin[ORB_MAX_PARTS - 1] = {};
     int parts = 2;
     DevBuf dGeom, dAreaTaps, dLinTaps, dCodeTab, dInput, dPyr, dCellKeys, dCellCount, dSort, dNodes, dInts,
-        dSelXY, dSelScore, dLevelCount, dLevelKeys, dError, dKps, dDesc, dNOut, dTmpA, dTmpB;
+        dSelXY, dSelScore, dLevelCount, dLevelKeys, dTmpA, dTmpB;
+    // One block for what the kernels report and what the host-pointer entry points read back, so that one copy
+    // fetches it all: [error flag word (64 bytes) | keypoint counts | keypoints (cap per frame) | descriptors].  The
+    // error flag word is used by every entry point; the
+    // rest is laid out per call for the call's frame count (orb_extract_batch).
+    DevBuf dHostOut;
+    int* dErr() const { return (int*)dHostOut.p; }
     PinBuf pinIn, pinOut;  // host-pointer entry points only, sized on first use
-    // The quadtree kernel's LDS block holds a level's keys; how many FAST hands over is only known on the
-    // device.  The kernel keeps the largest count it met next to the error word, every batch sends it to
-    // pinSeen without waiting, and the next batches size the block from what has arrived (a level with
-    // more keys than the block holds runs from global memory: slower, same result).
-    PinBuf pinSeen;
-    hipEvent_t evSeen = nullptr;
-    bool seenPending = false;
-    int seenKeys = 0;
     int lastFrames = 0;
     int inputStride = 0;
     const uint8_t* lastImg0 = nullptr;
@@ -293,6 +291,73 @@ static int check_tile_spans(int ssize, int dsize, int tile, const OrbAreaTap* at
 
 static inline int halfUp(int v) { return (v + 1) >> 1; }
 
+// Regions of the few-frames pyramid kernel (OrbGeom::chainX / chainY) from the tap tables: top level first, every
+// lower level's region is what the tile owns there joined with every source index the region above is made from.
+static void build_chain(OrbGeom& g, const std::vector<OrbAreaTap>& at, const std::vector<OrbLinTap>& lt) {
+    const bool area = (g.quirks & ORB_Q_RESIZE_AREA) != 0;
+    const int L = g.nlevels;
+    g.chainGX = g.chainGY = g.chainLds = 0;
+    if (L < 2) return;
+    const int GX = std::max(1, std::min(ORB_CHAIN_G, (g.w + 79) / 80)), GY = std::max(1, std::min(ORB_CHAIN_G, (g.h + 79) / 80));
+    auto axis = [&](bool isX, int G, short tab[][ORB_CHAIN_G][4]) {
+        for (int i = 0; i < G; i++) {
+            int r0 = 0, r1 = 0;
+            for (int k = L - 1; k >= 0; k--) {
+                const int size = isX ? g.lv[k].w : g.lv[k].h;
+                const int o0 = (int)((int64_t)i * size / G), o1 = (int)((int64_t)(i + 1) * size / G);
+                int n0 = o0, n1 = o1;  // what is needed at this level
+                if (k < L - 1 && r1 > r0) {  // sources of the region above
+                    const int tb = isX ? g.lv[k + 1].tabX : g.lv[k + 1].tabY;
+                    int lo = size, hi = -1;
+                    for (int d = r0; d < r1; d++) {
+                        if (area) {
+                            const OrbAreaTap& t = at[(size_t)tb + d];
+                            lo = std::min(lo, t.si[0]);
+                            for (int j = 0; j < ORB_MAX_TAPS; j++) hi = std::max(hi, t.si[j]);  // (unused taps name the last used cell)
+                        } else {
+                            const OrbLinTap& t = lt[(size_t)tb + d];
+                            lo = std::min(lo, std::min(t.s0, t.s1));
+                            hi = std::max(hi, std::max(t.s0, t.s1));
+                        }
+                    }
+                    if (o1 > o0) {
+                        n0 = std::min(o0, lo);
+                        n1 = std::max(o1, hi + 1);
+                    } else {
+                        n0 = lo;
+                        n1 = hi + 1;
+                    }
+                }
+                if (k == 0 && isX) n0 &= ~3;  // level 0 is read as dwords
+                tab[k][i][0] = (short)n0;
+                tab[k][i][1] = (short)n1;
+                tab[k][i][2] = (short)o0;
+                tab[k][i][3] = (short)o1;
+                r0 = n0;
+                r1 = n1;
+            }
+        }
+    };
+    axis(true, GX, g.chainX);
+    axis(false, GY, g.chainY);
+    size_t most = 0;
+    int widest = 0;
+    for (int k = 0; k < L; k++)
+        for (int i = 0; i < GX; i++)
+            for (int j = 0; j < GY; j++) {
+                const int pw = ((g.chainX[k][i][1] - g.chainX[k][i][0]) + 3) & ~3;
+                most = std::max(most, (size_t)pw * (size_t)(g.chainY[k][j][1] - g.chainY[k][j][0]));
+                widest = std::max(widest, pw);
+            }
+    // two buffers, each with room for the dword reads that start at a row's last pixel; level 0 is staged by at most
+    // 128 threads per row
+    const size_t lds = 2 * ((most + 16 + 15) & ~(size_t)15);
+    if (lds > 64 * 1024 || widest / 4 > 128 || g.w > 32767 || g.h > 32767) return;
+    g.chainGX = GX;
+    g.chainGY = GY;
+    g.chainLds = (int)lds;
+}
+
 // Level sizes (src/ORBextractor.cc:917-918), FAST cell grid (:808-823), quadtree
 // roots (:574-576) and every derived capacity for a w x h frame.
 static int compute_geom(orb_ctx* c, int w, int h) {
@@ -467,6 +532,7 @@ static int compute_geom(orb_ctx* c, int w, int h) {
     for (const OrbAreaTap& t : at)
         for (int j = 1; j < ORB_MAX_TAPS; j++)
             if (t.a[j] != 0.f) g.areaTapsMax = std::max(g.areaTapsMax, j + 1);
+    build_chain(g, at, lt);
     c->geom = g;
     c->areaTaps.swap(at);
     c->linTaps.swap(lt);
@@ -522,9 +588,10 @@ static int ensure_buffers(orb_ctx* c, int n) {
     if ((rc = c->dSelScore.ensure((size_t)n * g.outCapFrame * 4))) return rc;
     if ((rc = c->dLevelCount.ensure((size_t)n * g.nlevels * 4))) return rc;
     if ((rc = c->dLevelKeys.ensure((size_t)n * g.nlevels * 4))) return rc;
-    if (!c->dError.p) {
-        if ((rc = c->dError.ensure(8))) return rc;  // flag word, then the largest per-level key count seen
-        HIP_TRY(hipMemset(c->dError.p, 0, 8));
+    if (!c->dHostOut.p) {
+        const size_t frames = (size_t)std::max(n, c->prm.max_batch), cap = (size_t)orb_max_keypoints_per_frame(c);
+        if ((rc = c->dHostOut.ensure(64 + ((frames * 4 + 63) & ~(size_t)63) + frames * cap * (sizeof(orb_keypoint) + 32)))) return rc;
+        HIP_TRY(hipMemset(c->dHostOut.p, 0, 64));
     }
     return ORB_OK;
 }
@@ -578,26 +645,13 @@ extern "C" int orb_create(const orb_params* prm, orb_ctx** out) {
         CREATE_TRY(hipEventCreateWithFlags(&c->evJoin[i], hipEventDisableTiming));
     }
     CREATE_TRY(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
-    CREATE_TRY(hipEventCreateWithFlags(&c->evSeen, hipEventDisableTiming));
 #undef CREATE_TRY
-    {
-        int rcPin = c->pinSeen.ensure(64);
-        if (rcPin) {
-            orb_destroy(c);
-            return rcPin;
-        }
-        *(volatile int*)c->pinSeen.p = 0;
-    }
     // size everything for the largest announced frame and batch now, so steady-state calls allocate nothing
     int rc = compute_geom(c, prm->max_width, prm->max_height);
     if (rc == ORB_OK) rc = ensure_buffers(c, prm->max_batch);
     if (rc == ORB_OK) {
-        const int cap = orb_max_keypoints_per_frame(c);
         c->inputStride = (prm->max_width + 63) & ~63;
         rc = c->dInput.ensure((size_t)prm->max_batch * c->inputStride * prm->max_height);
-        if (rc == ORB_OK) rc = c->dKps.ensure((size_t)prm->max_batch * cap * sizeof(orb_keypoint));
-        if (rc == ORB_OK) rc = c->dDesc.ensure((size_t)prm->max_batch * cap * 32);
-        if (rc == ORB_OK) rc = c->dNOut.ensure((size_t)prm->max_batch * 4);
     }
     if (rc != ORB_OK) {
         orb_destroy(c);
@@ -613,13 +667,11 @@ extern "C" void orb_destroy(orb_ctx* c) {
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c->dGeom, &c->dAreaTaps, &c->dLinTaps, &c->dCodeTab, &c->dInput, &c->dPyr, &c->dCellKeys, &c->dCellCount,
                       &c->dSort, &c->dNodes, &c->dInts, &c->dSelXY, &c->dSelScore,
-                      &c->dLevelCount, &c->dLevelKeys, &c->dError, &c->dKps, &c->dDesc, &c->dNOut, &c->dTmpA,
+                      &c->dLevelCount, &c->dLevelKeys, &c->dHostOut, &c->dTmpA,
                       &c->dTmpB};
     for (DevBuf* b : bufs) b->release();
     c->pinIn.release();
     c->pinOut.release();
-    c->pinSeen.release();
-    if (c->evSeen) (void)hipEventDestroy(c->evSeen);
     if (c->matchState) orb_match_state_free(c->matchState);
     if (c->bowState) orb_bow_state_free(c->bowState);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -670,18 +722,9 @@ extern "C" int orb_compute_tables(const orb_params* prm, float* scale, float* in
     return orb_get_tables(&tmp, scale, inv_scale, sigma2, inv_sigma2, per_level, umax);
 }
 
-// Sends the device's largest-key-count word towards the host, unless an earlier copy is still under way.
-static int post_seen_keys(orb_ctx* c, hipStream_t st) {
-    if (c->seenPending) return ORB_OK;
-    HIP_TRY(hipMemcpyAsync(c->pinSeen.p, (const int*)c->dError.p + 1, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipEventRecord(c->evSeen, st));
-    c->seenPending = true;
-    return ORB_OK;
-}
-
 // Enqueue the whole extraction for n frames whose level 0 is at d_img0.
 static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int stride, int64_t frameStride,
-                     orb_keypoint* d_kps, uint8_t* d_desc, int cap, int* d_nOut, hipStream_t st) {
+                     orb_keypoint* d_kps, uint8_t* d_desc, int cap, int* d_nOut, hipStream_t st, int* d_status = nullptr) {
     if (n < 1 || n > c->prm.max_batch) {
         orb_set_error("batch of %d frames outside 1..max_batch=%d", n, c->prm.max_batch);
         return ORB_ERR_INVALID;
@@ -721,18 +764,13 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
     b.d_selScore = (int*)c->dSelScore.p;
     b.d_levelCount = (int*)c->dLevelCount.p;
     b.d_levelKeys = (int*)c->dLevelKeys.p;
-    b.d_error = (int*)c->dError.p;
+    b.d_error = c->dErr();
+    b.d_status = d_status;
     b.d_kps = d_kps;
     b.d_desc = d_desc;
     b.capPerFrame = cap;
     b.d_nOut = d_nOut;
     b.stream = st;
-    if (c->seenPending && hipEventQuery(c->evSeen) == hipSuccess) {
-        const int seen = *(volatile int*)c->pinSeen.p;
-        c->seenKeys = std::max(c->seenKeys, seen);
-        c->seenPending = false;
-    }
-    b.qtKeysSeen = c->seenKeys;
     c->lastImg0 = d_img0;
     c->lastStride0 = stride;
     c->lastFrameStride0 = frameStride;
@@ -748,7 +786,7 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
         HIP_TRY(hipEventRecord(ev[3], st));
         if ((rc = orb_launch_describe(b))) return rc;
         HIP_TRY(hipEventRecord(ev[4], st));
-        return post_seen_keys(c, st);
+        return ORB_OK;
     }
     const int parts = std::max(1, std::min(c->parts, n / ORB_MIN_PART_FRAMES));
     if (parts > 1) HIP_TRY(hipEventRecord(c->evFork, st));
@@ -775,16 +813,16 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
         HIP_TRY(hipEventRecord(c->evJoin[i - 1], c->aux[i - 1]));
         HIP_TRY(hipStreamWaitEvent(st, c->evJoin[i - 1], 0));
     }
-    return post_seen_keys(c, st);
+    return ORB_OK;
 }
 
 int orb_match_check_error(orb_ctx* c);  // kernels_match.hip
 
 static int read_error_flag(orb_ctx* c) {
     int flag = 0;
-    HIP_TRY(hipMemcpy(&flag, c->dError.p, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&flag, c->dErr(), 4, hipMemcpyDeviceToHost));
     if (flag) {
-        HIP_TRY(hipMemset(c->dError.p, 0, 4));
+        HIP_TRY(hipMemset(c->dErr(), 0, 4));
         orb_set_error("extraction hit an internal limit (flags 0x%x:%s%s%s%s%s)", flag,
                       (flag & 4) ? " key capacity" : "", (flag & 8) ? " node pool" : "",
                       (flag & 16) ? " quadtree depth" : "", (flag & 32) ? " level output" : "",
@@ -890,7 +928,19 @@ extern "C" int orb_extract_batch(orb_ctx* c, const uint8_t* const* imgs, int n, 
             orb_set_error("frame %d is null", f);
             return ORB_ERR_INVALID;
         }
-    {
+    const bool few = n < ORB_STAGE_SLICE;
+    if (few) {
+        // a few frames (the reference's one-frame-per-call use): one host thread, one copy
+        for (int f = 0; f < n; f++) {
+            uint8_t* dst = (uint8_t*)c->pinIn.p + f * fstride;
+            if (stride == dstride) {
+                memcpy(dst, imgs[f], (size_t)stride * (h - 1) + w);
+            } else {
+                for (int r = 0; r < h; r++) memcpy(dst + (size_t)r * dstride, imgs[f] + (size_t)r * stride, (size_t)w);
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(c->dInput.p, c->pinIn.p, (size_t)n * fstride, hipMemcpyHostToDevice, c->stream));
+    } else {
         const int nthreads = std::max(1, std::min(ORB_STAGE_THREADS, n / ORB_STAGE_SLICE));
         hipError_t terr[ORB_STAGE_THREADS];
         auto stage = [&](int t) {
@@ -916,20 +966,32 @@ extern "C" int orb_extract_batch(orb_ctx* c, const uint8_t* const* imgs, int n, 
         for (int t = 1; t < nthreads; t++) workers[t].join();
         for (int t = 0; t < nthreads; t++) HIP_TRY(terr[t]);
     }
-    rc = run_batch(c, (const uint8_t*)c->dInput.p, n, w, h, dstride, fstride, (orb_keypoint*)c->dKps.p,
-                   (uint8_t*)c->dDesc.p, cap, (int*)c->dNOut.p, c->stream);
-    if (rc) return rc;
-    // everything back in one go: [error flag | counts | keypoints (cap per frame) | descriptors], one synchronisation
+    // results: [flag words | counts | keypoints (cap per frame) | descriptors] as one block.  A batch leaves it in
+    // device memory and fetches it with one copy; a few frames write it straight into the page-locked host block
+    // (the last kernel stores the rows over the link itself: a copy between two kernels and the synchronisation
+    // costs more than the 64 KB per frame take), with the flag word as the last stage saw it per frame.
     const size_t offCnt = 64, offKps = offCnt + (((size_t)n * 4 + 63) & ~(size_t)63);
     const size_t offDesc = offKps + (size_t)n * cap * sizeof(orb_keypoint);
-    if ((rc = c->pinOut.ensure(offDesc + (size_t)n * cap * 32))) return rc;
+    const size_t total = offDesc + (size_t)n * cap * 32;
+    if ((rc = c->pinOut.ensure(total))) return rc;
     uint8_t* po = (uint8_t*)c->pinOut.p;
-    HIP_TRY(hipMemcpyAsync(po, c->dError.p, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(po + offCnt, c->dNOut.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    if (kps)
-        HIP_TRY(hipMemcpyAsync(po + offKps, c->dKps.p, (size_t)n * cap * sizeof(orb_keypoint), hipMemcpyDeviceToHost, c->stream));
-    if (desc) HIP_TRY(hipMemcpyAsync(po + offDesc, c->dDesc.p, (size_t)n * cap * 32, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    static_assert(ORB_STAGE_SLICE * sizeof(int) <= 64, "the per-frame flag words share the block's first 64 bytes");
+    if (few) {
+        uint8_t* dpo = nullptr;  // the block as the device addresses it
+        HIP_TRY(hipHostGetDevicePointer((void**)&dpo, po, 0));
+        rc = run_batch(c, (const uint8_t*)c->dInput.p, n, w, h, dstride, fstride, (orb_keypoint*)(dpo + offKps), dpo + offDesc,
+                       cap, (int*)(dpo + offCnt), c->stream, (int*)dpo);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int f = 1; f < n; f++) ((int*)po)[0] |= ((const int*)po)[f];
+    } else {
+        uint8_t* dOut = (uint8_t*)c->dHostOut.p;
+        rc = run_batch(c, (const uint8_t*)c->dInput.p, n, w, h, dstride, fstride, (orb_keypoint*)(dOut + offKps), dOut + offDesc,
+                       cap, (int*)(dOut + offCnt), c->stream);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(po, dOut, (kps || desc) ? (desc ? total : offDesc) : offKps, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     if (*(const int*)po != 0) return read_error_flag(c);
     memcpy(n_out, po + offCnt, (size_t)n * 4);
     for (int f = 0; f < n; f++) {

@@ -6,6 +6,8 @@
 #include "../../include/orb_hip.h"
 
 #define ORB_MAX_LEVELS 12
+#define ORB_FEW_FRAMES 8        // launches of fewer frames are bound by launch gaps and latency, not by throughput
+#define ORB_CHAIN_G 16          // most tiles per axis of the few-frames pyramid kernel
 #define ORB_MAX_TAPS 4          // source cells one destination pixel of the area resize may cover per axis
 #define ORB_EDGE 19             // EDGE_THRESHOLD, src/ORBextractor.cc:21
 #define ORB_BORDER 16           // EDGE_THRESHOLD - 3, src/ORBextractor.cc:808
@@ -58,6 +60,14 @@ struct OrbGeom {
     // group qi (bytes u0 .. u0 + 3, u0 = 4 * (qi + 1) - off - 21), word 0 holds 1 in every byte with |u| <= umax[|v|]
     // and word 1 holds u + 32 in those bytes (0 elsewhere).
     uint32_t icMask[4][31][9][2];
+    // Few-frames pyramid (one launch builds every level): the frame is cut into chainGX x chainGY tiles at every
+    // level alike (tile i of an axis of n pixels owns [i * n / G, (i + 1) * n / G)); chainX[level][i] = {r0, r1, o0,
+    // o1}: the columns [r0, r1) of that level the workgroup of tile column i computes (what it owns at [o0, o1) and
+    // whatever its part of the next level is made from), chainY alike for rows.  chainGX = 0: not available for
+    // this frame size.  chainLds: bytes of LDS the kernel needs.
+    int chainGX, chainGY, chainLds;
+    short chainX[ORB_MAX_LEVELS][ORB_CHAIN_G][4];
+    short chainY[ORB_MAX_LEVELS][ORB_CHAIN_G][4];
 };
 
 struct OrbAreaTap {  // one destination index of the area resize: up to 4 source cells and their weights
@@ -190,8 +200,8 @@ struct OrbBatch {  // everything one extraction launch sequence needs
     int* d_selScore;            // [frame][outCapFrame]
     int* d_levelCount;          // [frame][nlevels] keypoints kept per level
     int* d_levelKeys;           // [frame][nlevels] keys handed to the quadtree (counted by the FAST kernel)
-    int* d_error;               // flag word, OR of limit bits; d_error[1] = largest per-level key count seen so far
-    int qtKeysSeen;             // the host's copy of that count (0 = none yet)
+    int* d_error;               // flag word, OR of limit bits
+    int* d_status;              // optional: per frame, the flag word as the last stage saw it (may be host memory)
     orb_keypoint* d_kps;
     uint8_t* d_desc;
     int capPerFrame;

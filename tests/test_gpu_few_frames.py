@@ -1,0 +1,64 @@
+"""Calls of a few frames take latency-oriented paths (one launch for the whole scale pyramid, results written
+straight to host memory); batches take the throughput paths.  Both must return the same bytes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(640, 480), (752, 480), (1241, 376), (253, 249), (333, 251), (1920, 1080), (2047, 1153)]
+
+
+def _frame(w, h, seed):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, (h // 8 + 2, w // 8 + 2), dtype=np.uint8)
+    img = np.kron(base, np.ones((8, 8), dtype=np.uint8))[:h, :w].astype(np.int32)
+    img += rng.integers(-20, 21, (h, w))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("quirks", [0x1F, 0x1E], ids=["area", "linear"])
+@pytest.mark.parametrize("w,h", SIZES)
+def test_few_frame_paths_match_the_batch_paths(w, h, quirks):
+    from orb_slam2_amd import binding
+
+    frames = [_frame(w, h, 100 + i) for i in range(3)]
+    big = binding.Context(1000, 1.2, 8, 20, 7, w, h, 8, 0, quirks)
+    res = big.extract_batch(frames + [frames[0]] * 5)  # eight frames: level-by-level pyramid, results by copy
+    kb, db = [r[0] for r in res], [r[1] for r in res]
+    ref_levels = [[big.pyramid_level(f, l) for l in range(8)] for f in range(3)]
+    one = binding.Context(1000, 1.2, 8, 20, 7, w, h, 3, 0, quirks)
+    for f in range(3):  # one frame per call
+        k, d = one.extract(frames[f])
+        for l in range(8):
+            assert np.array_equal(one.pyramid_level(0, l), ref_levels[f][l]), (f, l)
+        assert np.array_equal(k, kb[f]) and np.array_equal(d, db[f])
+    res = one.extract_batch(frames)  # three frames in one call
+    k3, d3 = [r[0] for r in res], [r[1] for r in res]
+    for f in range(3):
+        for l in range(8):
+            assert np.array_equal(one.pyramid_level(f, l), ref_levels[f][l]), (f, l)
+        assert np.array_equal(k3[f], kb[f]) and np.array_equal(d3[f], db[f])
+    big.close()
+    one.close()
+
+
+def test_few_frame_path_reports_the_callers_capacity():
+    """The flag word reaches the host without a copy of its own on this path."""
+    import ctypes as C
+
+    from orb_slam2_amd import binding
+
+    img = _frame(640, 480, 7)
+    ctx = binding.Context(1000, 1.2, 8, 20, 7, 640, 480, 1, 0, 0x1F)
+    k, d = ctx.extract(img)
+    assert len(k) > 100
+    cap = len(k) - 10
+    kps = np.zeros(cap, binding.KP_DTYPE)
+    desc = np.zeros((cap, 32), np.uint8)
+    n = C.c_int(0)
+    rc = binding.lib().orb_extract(ctx.h, img.ctypes.data_as(C.c_void_p), 640, 480, 640, kps.ctypes.data_as(C.c_void_p),
+                                   desc.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+    assert rc != 0
+    k2, d2 = ctx.extract(img)  # and the context works on
+    assert np.array_equal(k, k2) and np.array_equal(d, d2)
+    ctx.close()
