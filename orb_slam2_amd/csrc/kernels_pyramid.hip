@@ -346,7 +346,7 @@ static int launch_resize(bool area, int ntaps, const uint8_t* src, int sw, int s
 // that of k_resize_tiled: same products, same sums, same order.
 #define PF_THREADS 1024
 #define PF_COLS 128  // threads along x; the eight wavefront pairs of a workgroup take rows in turn
-template <bool AREA>
+template <bool AREA, int NT>
 __global__ __launch_bounds__(PF_THREADS) void k_pyramid_few(const OrbGeom* __restrict__ g, const uint8_t* __restrict__ img0,
                                                             int stride0, int64_t frameStride0, uint8_t* __restrict__ pyr,
                                                             int frame0, const void* __restrict__ taps, int bufBytes) {
@@ -404,13 +404,13 @@ __global__ __launch_bounds__(PF_THREADS) void k_pyramid_few(const OrbGeom* __res
                     const OrbAreaTap ty = ((const OrbAreaTap*)taps)[L.tabY + y];
                     float s = 0.f;
 #pragma unroll
-                    for (int j = 0; j < ORB_MAX_TAPS; j++) {
+                    for (int j = 0; j < NT; j++) {  // (taps beyond NT have weight 0 in every table of this geometry)
                         const uint32_t* p = rowp + (ty.si[j] - ry0) * rowStep;
                         const uint32_t w = __builtin_amdgcn_alignbyte(p[1], p[0], sh);
                         float buf = (float)(w & 255u) * tx.a[0];
                         buf = buf + (float)((w >> 8) & 255u) * tx.a[1];
                         buf = buf + (float)((w >> 16) & 255u) * tx.a[2];
-                        buf = buf + (float)(w >> 24) * tx.a[3];
+                        if (NT > 3) buf = buf + (float)(w >> 24) * tx.a[3];
                         s = (j == 0) ? buf * ty.a[0] : s + buf * ty.a[j];
                     }
                     const uint8_t v = (uint8_t)(__builtin_amdgcn_cvt_pk_u8_f32(s, 0u, 0u) & 255u);  // saturate_cast<uchar>
@@ -446,11 +446,14 @@ static int launch_pyramid_few(const OrbBatch& b) {
     const bool area = (g.quirks & ORB_Q_RESIZE_AREA) != 0;
     const int bufBytes = g.chainLds / 2;
     const dim3 grid((unsigned)(b.nframes * g.chainGX * g.chainGY));
-    if (area)
-        hipLaunchKernelGGL(k_pyramid_few<true>, grid, dim3(PF_THREADS), (size_t)g.chainLds, (hipStream_t)b.stream, b.d_geom,
+    if (area && g.areaTapsMax <= 3)
+        hipLaunchKernelGGL((k_pyramid_few<true, 3>), grid, dim3(PF_THREADS), (size_t)g.chainLds, (hipStream_t)b.stream, b.d_geom,
+                           b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, (const void*)b.d_areaTaps, bufBytes);
+    else if (area)
+        hipLaunchKernelGGL((k_pyramid_few<true, ORB_MAX_TAPS>), grid, dim3(PF_THREADS), (size_t)g.chainLds, (hipStream_t)b.stream, b.d_geom,
                            b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, (const void*)b.d_areaTaps, bufBytes);
     else
-        hipLaunchKernelGGL(k_pyramid_few<false>, grid, dim3(PF_THREADS), (size_t)g.chainLds, (hipStream_t)b.stream, b.d_geom,
+        hipLaunchKernelGGL((k_pyramid_few<false, 2>), grid, dim3(PF_THREADS), (size_t)g.chainLds, (hipStream_t)b.stream, b.d_geom,
                            b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, (const void*)b.d_linTaps, bufBytes);
     return check_launch("pyramid");
 }

@@ -298,7 +298,10 @@ static void build_chain(OrbGeom& g, const std::vector<OrbAreaTap>& at, const std
     const int L = g.nlevels;
     g.chainGX = g.chainGY = g.chainLds = 0;
     if (L < 2) return;
-    const int GX = std::max(1, std::min(ORB_CHAIN_G, (g.w + 79) / 80)), GY = std::max(1, std::min(ORB_CHAIN_G, (g.h + 79) / 80));
+    // tiles of about 40 pixels at level 0: at 640x480 192 workgroups, each computing ~4x what it owns (borders
+    // included); coarser tiles recompute less but leave most of the device idle (measured: 80 -> 31 us, 40 -> 20 us)
+    const int tileSide = 40;
+    const int GX = std::max(1, std::min(ORB_CHAIN_G, (g.w + tileSide - 1) / tileSide)), GY = std::max(1, std::min(ORB_CHAIN_G, (g.h + tileSide - 1) / tileSide));
     auto axis = [&](bool isX, int G, short tab[][ORB_CHAIN_G][4]) {
         for (int i = 0; i < G; i++) {
             int r0 = 0, r1 = 0;
