@@ -230,26 +230,4 @@ int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, std::vector<MapPoint*>& vpM
 }
 #endif
 
-// src/ORBmatcher.cc:413-454 (host helper kept for callers; the kernels carry their own copy).
-void ORBmatcher::ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {
-    int max1 = 0, max2 = 0, max3 = 0;
-    for (int i = 0; i < L; i++) {
-        const int s = (int)histo[i].size();
-        if (s > max1) {
-            max3 = max2; max2 = max1; max1 = s;
-            ind3 = ind2; ind2 = ind1; ind1 = i;
-        } else if (s > max2) {
-            max3 = max2; max2 = s;
-            ind3 = ind2; ind2 = i;
-        } else if (s > max3) {
-            max3 = s; ind3 = i;
-        }
-    }
-    if (max2 < 0.1f * (float)max1) {
-        ind2 = -1; ind3 = -1;
-    } else if (max3 < 0.1f * (float)max1) {
-        ind3 = -1;
-    }
-}
-
 }  // namespace ORB_SLAM2

@@ -71,7 +71,8 @@ protected:
                         const cv::Mat& descriptorsKF, const DBoW2::FeatureVector& vFeatVecKF, Frame& F,
                         std::vector<MapPoint*>& vpMapPointMatches);
     float RadiusByViewingCos(const float& viewCos);  // include/ORBmatcher.h:197
-    void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3);
+    // (ComputeThreeMaxima, include/ORBmatcher.h:198, is a protected helper of the reference's host loops; here the
+    // rotation histogram and its three maxima are part of the matching kernels, so the class has no such member)
 
     float mfNNratio;
     bool mbCheckOrientation;

@@ -53,7 +53,7 @@ def test_libm_vs_portable_trig_descriptor_difference(oracle):
     """The reference calls libm cos/sin (src/ORBextractor.cc:70); the oracle's default is a portable
     routine shared in specification with the GPU.  Report how many descriptors differ between the two
     on the fixtures' frames (expected: none or a handful of bits; never hidden)."""
-    total = diff = 0
+    total = diff = bits = 0
     for (w, h, seed) in [(640, 480, 185527048), (752, 480, 3 * 1000003 + 0x0B5EED00)]:
         img = synth_scene(w, h, seed)
         a = oracle.Extractor(1000, 1.2, 8, 20, 7, oracle.QUIRKS_FORK)
@@ -63,5 +63,6 @@ def test_libm_vs_portable_trig_descriptor_difference(oracle):
         assert (ka == kb).all()
         total += len(da)
         diff += int((da != db_).any(axis=1).sum())
-    print("descriptors differing between libm and portable trig: %d of %d" % (diff, total))
+        bits += int(np.unpackbits(da ^ db_).sum())
+    print("descriptors differing between libm and portable trig: %d of %d (%d of %d bits)" % (diff, total, bits, total * 256))
     assert diff <= total // 100
