@@ -17,13 +17,20 @@
 
 #define DESC_WAVES 1  // wavefronts per workgroup; with one, a keypoint's LDS is free again as soon as its wavefront ends
 #define RAW_N 43
-#define RAW_P 48   // 12 dwords: a window row starting at any byte alignment fits
+#define RAW_DW 12  // dwords fetched per window row: a row starting at any byte alignment fits
+#ifndef RAW_P
+#define RAW_P 48   // LDS pitch of the window rows
+#endif
 #define HGROUPS 10 // 4-column groups that hold the 37 blurred columns off+3 .. off+39, from group (off+3)/4 on
 #define HROWS 6    // rows (or row pairs) the 64 lanes take per pass: lane = (row, group), lanes 60..63 idle
+#ifndef HB_P
 #define HB_P 40    // horizontal sums (16 bit) of a row pair per column of those groups: one dword each
+#endif
 #define HB_PAIRS 22  // row pairs (0,1) .. (42,43); row 43 does not exist, its sums meet weight 0 only
 #define BL_N 37
+#ifndef BL_P
 #define BL_P 44
+#endif
 
 // the 256 test pairs of src/ORBextractor.cc:105-362 as (x0, x1, y0, y1), kept as floats for the rotation
 __constant__ __attribute__((aligned(16))) float c_pattern[256 * 4] = {
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     // take bytes, reflected at the borders like the blur's BORDER_REFLECT_101.
     const int wx0 = px - 21, wy0 = py - 21;
     const int xa = wx0 & ~3;
-    const bool fastLoad = wx0 >= 0 && wy0 >= 0 && py + 21 < L.h && xa + RAW_P <= L.w && (pitch & 3) == 0 &&
+    const bool fastLoad = wx0 >= 0 && wy0 >= 0 && py + 21 < L.h && xa + 4 * RAW_DW <= L.w && (pitch & 3) == 0 &&
                           (((unsigned long long)img) & 3ull) == 0;
     const int off = fastLoad ? (wx0 - xa) : 0;
     // the IC_Angle byte weights of this lane's five patch rows: requested now, used after the window is staged
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     if (fastLoad) {
         // lane = (row within a group of five, dword); nine groups cover the 43 rows, all loads in flight at once.
         // The window's origin is the same for all lanes (scalar 64-bit address), a lane adds a 32-bit offset.
-        const int rr = lane_div<RAW_P / 4>(lane), d = lane - rr * (RAW_P / 4);
+        const int rr = lane_div<RAW_DW>(lane), d = lane - rr * RAW_DW;
         if (rr < 5) {
             // (the stride of five rows goes through a lane read so that it stays a plain addend: folded into
             // the address it becomes one quarter-rate 64-bit multiply-add per row)
