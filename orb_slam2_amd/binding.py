@@ -148,6 +148,18 @@ class Context:
         _check(lib().orb_extract_batch(self.h, ptrs, n, w, h, imgs[0].strides[0], _p(kps), _p(desc), self.cap, _p(cnt)))
         return [(kps[f, : cnt[f]].copy(), desc[f, : cnt[f]].copy()) for f in range(n)]
 
+    def extract_batch_into(self, imgs, kps, desc, cnt):
+        """orb_extract_batch into arrays the caller keeps (kps [n, cap] KP_DTYPE, desc [n, cap, 32] uint8, cnt [n]
+        int32): nothing is allocated per call, which is half the time of a 64-frame call otherwise.  Returns cnt."""
+        n = len(imgs)
+        h, w = imgs[0].shape
+        assert all(i.shape == (h, w) and i.dtype == np.uint8 and i.strides == imgs[0].strides for i in imgs)
+        assert kps.shape == (n, self.cap) and desc.shape == (n, self.cap, 32) and cnt.shape == (n,)
+        assert kps.flags.c_contiguous and desc.flags.c_contiguous and cnt.dtype == np.int32
+        ptrs = (C.c_void_p * n)(*[i.ctypes.data for i in imgs])
+        _check(lib().orb_extract_batch(self.h, ptrs, n, w, h, imgs[0].strides[0], _p(kps), _p(desc), self.cap, _p(cnt)))
+        return cnt
+
     # ---- extraction, device tensors ----------------------------------------------------
     def extract_batch_device(self, d_imgs, d_kps, d_desc, d_counts, stream=None):
         """d_imgs: uint8 CUDA tensor [n, h, w] (any row / frame stride); outputs are

@@ -85,7 +85,7 @@ struct PinBuf {  // page-locked host staging: one DMA per direction instead of p
 };
 
 #define ORB_MAX_PARTS 4
-#define ORB_STAGE_THREADS 4      // host threads that stage a batch of host frames
+#define ORB_STAGE_THREADS 16     // most host threads that stage a batch of host frames (orb_ctx::stageThreads are used)
 #define ORB_STAGE_SLICE 4        // frames per host-to-device copy
 #define ORB_MIN_PART_FRAMES 8   // groups smaller than this do not fill the device; the batch is then not split
 
@@ -107,6 +107,7 @@ struct orb_ctx {
     hipStream_t aux[ORB_MAX_PARTS - 1] = {};
     hipEvent_t evFork = nullptr, evJoin[ORB_MAX_PARTS - 1] = {};
     int parts = 2;
+    int stageThreads = 4;
     DevBuf dGeom, dAreaTaps, dLinTaps, dCodeTab, dInput, dPyr, dCellKeys, dCellCount, dSort, dNodes, dInts,
         dSelXY, dSelScore, dLevelCount, dLevelKeys, dTmpA, dTmpB;
     // One block for what the kernels report and what the host-pointer entry points read back, so that one copy
@@ -643,6 +644,7 @@ extern "C" int orb_create(const orb_params* prm, orb_ctx** out) {
     // one extra stream per frame group beyond the first: a process has few hardware queues (four by default),
     // and streams that share one serialise, so a context takes no more than it will use
     if (const char* e = getenv("ORBHIP_PARTS")) c->parts = std::max(1, std::min(ORB_MAX_PARTS, atoi(e)));
+    if (const char* e = getenv("ORBHIP_STAGE_THREADS")) c->stageThreads = std::max(1, std::min(ORB_STAGE_THREADS, atoi(e)));
     for (int i = 0; i < c->parts - 1; i++) {
         CREATE_TRY(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
         CREATE_TRY(hipEventCreateWithFlags(&c->evJoin[i], hipEventDisableTiming));
@@ -944,7 +946,7 @@ extern "C" int orb_extract_batch(orb_ctx* c, const uint8_t* const* imgs, int n, 
         }
         HIP_TRY(hipMemcpyAsync(c->dInput.p, c->pinIn.p, (size_t)n * fstride, hipMemcpyHostToDevice, c->stream));
     } else {
-        const int nthreads = std::max(1, std::min(ORB_STAGE_THREADS, n / ORB_STAGE_SLICE));
+        const int nthreads = std::max(1, std::min(c->stageThreads, n / ORB_STAGE_SLICE));
         hipError_t terr[ORB_STAGE_THREADS];
         auto stage = [&](int t) {
             terr[t] = t ? hipSetDevice(c->prm.device) : hipSuccess;

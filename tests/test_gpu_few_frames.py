@@ -62,3 +62,20 @@ def test_few_frame_path_reports_the_callers_capacity():
     k2, d2 = ctx.extract(img)  # and the context works on
     assert np.array_equal(k, k2) and np.array_equal(d, d2)
     ctx.close()
+
+
+def test_batch_into_arrays_the_caller_keeps():
+    from orb_slam2_amd import binding
+
+    frames = [_frame(640, 480, 300 + i) for i in range(9)]
+    ctx = binding.Context(1000, 1.2, 8, 20, 7, 640, 480, 9, 0, 0x1F)
+    ref = ctx.extract_batch(frames)
+    kps = np.zeros((9, ctx.cap), binding.KP_DTYPE)
+    desc = np.zeros((9, ctx.cap, 32), np.uint8)
+    cnt = np.zeros(9, np.int32)
+    for _ in range(2):  # the second call finds the first one's rows in the arrays
+        ctx.extract_batch_into(frames, kps, desc, cnt)
+        for f in range(9):
+            assert cnt[f] == len(ref[f][0])
+            assert np.array_equal(kps[f, : cnt[f]], ref[f][0]) and np.array_equal(desc[f, : cnt[f]], ref[f][1])
+    ctx.close()
