@@ -160,6 +160,7 @@ def main():
         step()
     torch.cuda.synchronize()
     stage_ms, nrec = ctx.stage_timings()
+    qt_second = ctx.quadtree_second_pass_levels()  # of the last batch: (frame, level) pairs that needed the finer histogram
     ctx.enable_stage_timing(False)
     ctx.check_last_batch()
     nstep[0] = 0
@@ -215,6 +216,7 @@ def main():
         "algorithmic_bytes_per_launch": int(stage_bytes[dom] * B), "launch_ms": round(stage_ms[dom], 4),
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}, "stage_batches": nrec,
         "stage_timing": "HIP events between the stages, same steps repeated after the timed loop with group overlap off",
+        "quadtree_second_pass_levels": qt_second, "quadtree_levels_per_batch": B * 8,
     }
 
     # ---- brute-force Hamming ------------------------------------------------------------

@@ -98,6 +98,14 @@ int orb_extract_batch_device(orb_ctx* ctx, const uint8_t* d_imgs, int n, int w, 
                              int64_t frame_stride, orb_keypoint* d_kps, uint8_t* d_desc, int cap_per_frame,
                              int* d_n_out, void* stream);
 
+/* Diagnostics.  A batch of about a hundred frames or more distributes its keypoints (DistributeOctTree,
+ * src/ORBextractor.cc:571-796) in two passes: the first with coarse per-level histograms, which settles the levels
+ * whose keypoints are spread as in ordinary images, the second with finer ones for the levels that crowd their
+ * keypoints into a small part of the frame.  Results do not depend on the pass; throughput does.  Waits for the
+ * device and reports how many (frame, level) pairs of the context's last batch went to the second pass (0 for
+ * smaller batches and for frames above ~2K, which run one pass). */
+int orb_quadtree_second_pass_levels(orb_ctx* ctx, int* levels);
+
 /* After *_device calls have completed: 0 if no internal capacity or depth
  * limit was hit by the extraction batches and windowed-matcher calls since the
  * last check, else ORB_ERR_CAPACITY (synchronises). */

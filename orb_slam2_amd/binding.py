@@ -26,7 +26,7 @@ KP_DTYPE = np.dtype(
 
 EXPORTS = [
     "orb_create", "orb_destroy", "orb_max_keypoints_per_frame", "orb_extract", "orb_extract_batch",
-    "orb_extract_batch_device", "orb_check_last_batch", "orb_get_pyramid_level", "orb_get_pyramid", "orb_get_tables",
+    "orb_extract_batch_device", "orb_check_last_batch", "orb_quadtree_second_pass_levels", "orb_get_pyramid_level", "orb_get_pyramid", "orb_get_tables",
     "orb_compute_tables",
     "orb_debug_get_fast_keys", "orb_resize", "orb_gaussian_blur", "orb_hamming", "orb_match_window",
     "orb_match_window_batch_device", "orb_match_reserve_candidates", "orb_match_projected", "orb_bf_create", "orb_bf_destroy", "orb_bf_set_database",
@@ -180,6 +180,11 @@ class Context:
         n = C.c_int(0)
         _check(lib().orb_get_stage_timings(self.h, ms, C.byref(n)))
         return dict(pyramid=ms[0], fast=ms[1], quadtree=ms[2], describe=ms[3]), n.value
+
+    def quadtree_second_pass_levels(self):
+        n = C.c_int(0)
+        _check(lib().orb_quadtree_second_pass_levels(self.h, C.byref(n)))
+        return n.value
 
     def check_last_batch(self):
         _check(lib().orb_check_last_batch(self.h))

@@ -44,6 +44,10 @@ struct QtLaunch {
     int binBits;          // key-sort buckets = 2^binBits (sorted form)
     int regionInts;       // ints behind the keys: histogram or bucket arrays, then node scratch
     unsigned nframesMagic;  // orb_div_magic(frames of the launch)
+    // 0: every (frame, level) is finished by its workgroup.  A batch runs in two passes instead: pass 1 with one
+    // path digit fewer buckets (a quarter of the LDS, twice the workgroups per CU), whose workgroups hand the
+    // levels that need the finer buckets to a list; pass 2 takes the list with the full depth.
+    int pass;
 };
 
 // Path of a key from its rank (= cell * cellCap + position inside the cell): the histogram form needs it for
@@ -130,25 +134,20 @@ static __device__ __forceinline__ void qt_work_global(QtWork* w, const OrbGeom* 
     w->scanC = p;
 }
 
-__global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __restrict__ g, const QtLaunch q, int frame0, int nframes,
-                                                        const uint32_t* __restrict__ cellKeys,
-                                                        const int* __restrict__ cellCount,
-                                                        const uint32_t* __restrict__ codeTab,
-                                                        unsigned long long* __restrict__ sortBuf,
-                                                        OrbNode* __restrict__ nodes, int* __restrict__ ints,
-                                                        uint32_t* __restrict__ selXY, int* __restrict__ selScore,
-                                                        int* __restrict__ levelCount, int* __restrict__ levelKeys,
-                                                        int* __restrict__ error) {
-    static_assert(sizeof(QtShared) <= QT_STATIC_LDS, "QtShared outgrew its bound");
-    __shared__ QtShared sh;
-    extern __shared__ unsigned long long s_dyn[];  // q.ldsKeys entries, then q.regionInts ints
-    unsigned long long* const s_keys = s_dyn;
-    int* const s_region = (int*)(s_dyn + q.ldsKeys);
+// One (frame, level): `wg` is its number in the level-major order of the launch.
+static __device__ __forceinline__ void qt_one(const OrbGeom* __restrict__ g, const QtLaunch& q, int wg, int frame0, int nframes,
+                                              const uint32_t* __restrict__ cellKeys, const int* __restrict__ cellCount,
+                                              const uint32_t* __restrict__ codeTab, unsigned long long* __restrict__ sortBuf,
+                                              OrbNode* __restrict__ nodes, int* __restrict__ ints,
+                                              uint32_t* __restrict__ selXY, int* __restrict__ selScore,
+                                              int* __restrict__ levelCount, int* __restrict__ levelKeys,
+                                              int* __restrict__ retry, int* __restrict__ error, QtShared& sh,
+                                              unsigned long long* s_keys, int* s_region) {
     const QtBins bins = {s_region, s_region + (1 << q.binBits) + 1, q.binBits};
     const int nlevels = g->nlevels;
     // level-major launch order: the levels with the most keys (the longest-running workgroups) start first
-    const int levelLocal = (int)orb_div(blockIdx.x, (unsigned)nframes, q.nframesMagic);
-    const int level = q.level0 + levelLocal, frame = frame0 + (int)blockIdx.x - levelLocal * nframes;
+    const int levelLocal = (int)orb_div((unsigned)wg, (unsigned)nframes, q.nframesMagic);
+    const int level = q.level0 + levelLocal, frame = frame0 + wg - levelLocal * nframes;
     const OrbLevel& L = g->lv[level];
     const int t = threadIdx.x, T = (int)blockDim.x;
     unsigned long long* sortedG = sortBuf + ((int64_t)frame * g->keysPerFrame + L.keyBase) * 2;
@@ -164,7 +163,7 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __re
     QT_STAMP(0);
 
     // ---- histogram form ------------------------------------------------------------------------------
-    const int Db = L.histDepth, nb = L.nIni << (2 * Db);
+    const int Db = q.pass == 1 ? L.histDepthFirst : L.histDepth, nb = L.nIni << (2 * Db);
     if (2 * nb + 1 <= q.regionInts) {
         int* start = s_region;
         uint32_t* best = (uint32_t*)(s_region + nb + 1);
@@ -251,7 +250,11 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __re
 #endif
             return;
         }
-        __syncthreads();  // a node below the bucket depth holds several keys: the sorted form takes the level
+        if (q.pass == 1) {  // a node below the bucket depth holds several keys: the second pass takes the level
+            if (t == 0) retry[1 + atomicAdd(&retry[0], 1)] = wg;
+            return;
+        }
+        __syncthreads();  // ... or, without a second pass (or in it), the sorted form does
     }
 
     // ---- sorted form ---------------------------------------------------------------------------------
@@ -307,19 +310,48 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __re
     if (t == 0) levelCount[frame * nlevels + level] = count;
 }
 
+__global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __restrict__ g, const QtLaunch q, int frame0, int nframes,
+                                                        const uint32_t* __restrict__ cellKeys,
+                                                        const int* __restrict__ cellCount,
+                                                        const uint32_t* __restrict__ codeTab,
+                                                        unsigned long long* __restrict__ sortBuf,
+                                                        OrbNode* __restrict__ nodes, int* __restrict__ ints,
+                                                        uint32_t* __restrict__ selXY, int* __restrict__ selScore,
+                                                        int* __restrict__ levelCount, int* __restrict__ levelKeys,
+                                                        int* __restrict__ retry, int* __restrict__ error) {
+    static_assert(sizeof(QtShared) <= QT_STATIC_LDS, "QtShared outgrew its bound");
+    __shared__ QtShared sh;
+    extern __shared__ unsigned long long s_dyn[];  // q.ldsKeys entries, then q.regionInts ints
+    unsigned long long* const s_keys = s_dyn;
+    int* const s_region = (int*)(s_dyn + q.ldsKeys);
+    if (q.pass != 2) {
+        qt_one(g, q, (int)blockIdx.x, frame0, nframes, cellKeys, cellCount, codeTab, sortBuf, nodes, ints, selXY, selScore, levelCount,
+               levelKeys, retry, error, sh, s_keys, s_region);
+        return;
+    }
+    // second pass: the levels the first pass listed (its launch is complete: same stream), a few per workgroup
+    const int listed = retry[0];
+    for (int i = (int)blockIdx.x; i < listed; i += (int)gridDim.x) {
+        qt_one(g, q, retry[1 + i], frame0, nframes, cellKeys, cellCount, codeTab, sortBuf, nodes, ints, selXY, selScore, levelCount,
+               levelKeys, retry, error, sh, s_keys, s_region);
+        __syncthreads();
+    }
+}
+
 // LDS block of a launch over all levels.  The histogram arrays (2 nb + 1 ints for nb buckets) and the node
 // scratch behind them decide it; the sorted form, which only levels the histogram form gives up on take, puts
 // its bucket arrays over the same words, keeps its sorted keys in global memory and its node scratch wherever
 // the histogram form had it.
-static QtLaunch qt_plan(const OrbGeom& g, bool bigFrames) {
+static QtLaunch qt_plan(const OrbGeom& g, bool bigFrames, int pass) {
     QtLaunch q;
+    q.pass = pass;
     q.level0 = 0;
     q.nlevels = g.nlevels;
     q.ldsKeys = 0;
     q.nframesMagic = 0;
     int hist = 0, both = 0;
     for (int l = 0; l < g.nlevels; l++) {
-        const int h = 2 * (g.lv[l].nIni << (2 * g.lv[l].histDepth)) + 1;
+        const int h = 2 * (g.lv[l].nIni << (2 * (pass == 1 ? g.lv[l].histDepthFirst : g.lv[l].histDepth))) + 1;
         hist = std::max(hist, h);
         both = std::max(both, h + QT_NODE_INTS(g.lv[l].nodeCap));
     }
@@ -332,12 +364,10 @@ static QtLaunch qt_plan(const OrbGeom& g, bool bigFrames) {
     return q;
 }
 
-int orb_launch_quadtree(const OrbBatch& b) {
+static int qt_launch(const OrbBatch& b, bool bigFrames, int pass) {
     const OrbGeom& g = *b.h_geom;
-    // large levels (4K frames hand ~1e5 keys to the quadtree) get a full 1024-thread workgroup
-    const bool bigFrames = g.lv[0].keyCap > ORB_QT_BIG_KEYCAP;
     const int threads = bigFrames ? 1024 : 256;
-    QtLaunch q = qt_plan(g, bigFrames);
+    QtLaunch q = qt_plan(g, bigFrames, pass);
     q.nframesMagic = orb_div_magic((uint32_t)b.nframes, (uint64_t)b.nframes * q.nlevels);
     const size_t lds = (size_t)q.ldsKeys * 8 + (size_t)q.regionInts * 4;
     if (lds + QT_STATIC_LDS > 160 * 1024) {
@@ -355,13 +385,44 @@ int orb_launch_quadtree(const OrbBatch& b) {
             asked = true;
         }
     }
-    hipLaunchKernelGGL(k_quadtree, dim3(b.nframes * q.nlevels), dim3(threads), lds, (hipStream_t)b.stream, b.d_geom, q,
+    // every frame group of a batch has its own list (a count, then at most one entry per (frame, level))
+    int* retry = b.d_qtRetry + (int64_t)b.frame0 * (g.nlevels + 1);
+    const int all = b.nframes * q.nlevels;
+    if (pass == 1) {
+        hipError_t em = hipMemsetAsync(retry, 0, sizeof(int), (hipStream_t)b.stream);
+        if (em != hipSuccess) {
+            orb_set_error("quadtree: %s", hipGetErrorString(em));
+            return ORB_ERR_HIP;
+        }
+    }
+    hipLaunchKernelGGL(k_quadtree, dim3(pass == 2 ? std::min(all, 1024) : all), dim3(threads), lds, (hipStream_t)b.stream, b.d_geom, q,
                        b.frame0, b.nframes, b.d_cellKeys, b.d_cellCount, b.d_codeTab, b.d_sort, b.d_nodes, b.d_ints, b.d_selXY, b.d_selScore, b.d_levelCount,
-                       b.d_levelKeys, b.d_error);
+                       b.d_levelKeys, retry, b.d_error);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         orb_set_error("quadtree launch failed: %s", hipGetErrorString(e));
         return ORB_ERR_HIP;
     }
     return ORB_OK;
+}
+
+// A large batch is bound by how many workgroups a CU holds, a smaller one (all of whose workgroups are resident at
+// once anyway: 768 with the full-depth histograms) by the latency of one workgroup: two passes when the first one's
+// smaller histograms make a difference to the former.  ORBHIP_QT_TWO_PASS_MIN moves the threshold (tests).
+bool orb_quadtree_two_passes(const OrbGeom& g, int nframes) {
+    const char* e = getenv("ORBHIP_QT_TWO_PASS_MIN");
+    const int least = e ? atoi(e) : 768;
+    if (g.lv[0].keyCap > ORB_QT_BIG_KEYCAP || nframes * g.nlevels < least) return false;
+    for (int l = 0; l < g.nlevels; l++)
+        if (g.lv[l].histDepthFirst < g.lv[l].histDepth) return true;
+    return false;
+}
+
+int orb_launch_quadtree(const OrbBatch& b) {
+    const OrbGeom& g = *b.h_geom;
+    // large levels (4K frames hand ~1e5 keys to the quadtree) get a full 1024-thread workgroup
+    const bool bigFrames = g.lv[0].keyCap > ORB_QT_BIG_KEYCAP;
+    if (!orb_quadtree_two_passes(g, b.nframes)) return qt_launch(b, bigFrames, 0);
+    const int rc = qt_launch(b, bigFrames, 1);
+    return rc ? rc : qt_launch(b, bigFrames, 2);
 }

@@ -109,7 +109,7 @@ struct orb_ctx {
     int parts = 2;
     int stageThreads = 4;
     DevBuf dGeom, dAreaTaps, dLinTaps, dCodeTab, dInput, dPyr, dCellKeys, dCellCount, dSort, dNodes, dInts,
-        dSelXY, dSelScore, dLevelCount, dLevelKeys, dTmpA, dTmpB;
+        dSelXY, dSelScore, dLevelCount, dLevelKeys, dQtRetry, dTmpA, dTmpB;
     // One block for what the kernels report and what the host-pointer entry points read back, so that one copy
     // fetches it all: [error flag word (64 bytes) | keypoint counts | keypoints (cap per frame) | descriptors].  The
     // error flag word is used by every entry point; the
@@ -118,6 +118,7 @@ struct orb_ctx {
     int* dErr() const { return (int*)dHostOut.p; }
     PinBuf pinIn, pinOut;  // host-pointer entry points only, sized on first use
     int lastFrames = 0;
+    int lastGroups = 0, lastGroupFrame0[ORB_MAX_PARTS] = {};  // frame groups of the last batch whose quadtree ran in two passes
     int inputStride = 0;
     const uint8_t* lastImg0 = nullptr;
     int lastStride0 = 0;
@@ -518,6 +519,7 @@ static int compute_geom(orb_ctx* c, int w, int h) {
         // buckets of the quadtree's histogram form: 4096 at most where several workgroups share a CU's LDS,
         // 16384 for the levels of large frames, whose workgroups take a CU for themselves
         L.histDepth = qt_hist_depth(L.nIni, L.quota, g.lv[0].keyCap > ORB_QT_BIG_KEYCAP ? 16384 : 4096);
+        L.histDepthFirst = std::min(L.histDepth, qt_hist_depth(L.nIni, L.quota, 4096, 1));
     }
     g.cellsPerFrame = cellBase;
     g.cellCap = cellCap;
@@ -592,6 +594,7 @@ static int ensure_buffers(orb_ctx* c, int n) {
     if ((rc = c->dSelScore.ensure((size_t)n * g.outCapFrame * 4))) return rc;
     if ((rc = c->dLevelCount.ensure((size_t)n * g.nlevels * 4))) return rc;
     if ((rc = c->dLevelKeys.ensure((size_t)n * g.nlevels * 4))) return rc;
+    if ((rc = c->dQtRetry.ensure(((size_t)n * (g.nlevels + 1) + 1) * 4))) return rc;
     if (!c->dHostOut.p) {
         const size_t frames = (size_t)std::max(n, c->prm.max_batch), cap = (size_t)orb_max_keypoints_per_frame(c);
         if ((rc = c->dHostOut.ensure(64 + ((frames * 4 + 63) & ~(size_t)63) + frames * cap * (sizeof(orb_keypoint) + 32)))) return rc;
@@ -672,7 +675,7 @@ extern "C" void orb_destroy(orb_ctx* c) {
     (void)hipDeviceSynchronize();
     DevBuf* bufs[] = {&c->dGeom, &c->dAreaTaps, &c->dLinTaps, &c->dCodeTab, &c->dInput, &c->dPyr, &c->dCellKeys, &c->dCellCount,
                       &c->dSort, &c->dNodes, &c->dInts, &c->dSelXY, &c->dSelScore,
-                      &c->dLevelCount, &c->dLevelKeys, &c->dHostOut, &c->dTmpA,
+                      &c->dLevelCount, &c->dLevelKeys, &c->dQtRetry, &c->dHostOut, &c->dTmpA,
                       &c->dTmpB};
     for (DevBuf* b : bufs) b->release();
     c->pinIn.release();
@@ -769,6 +772,7 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
     b.d_selScore = (int*)c->dSelScore.p;
     b.d_levelCount = (int*)c->dLevelCount.p;
     b.d_levelKeys = (int*)c->dLevelKeys.p;
+    b.d_qtRetry = (int*)c->dQtRetry.p;
     b.d_error = c->dErr();
     b.d_status = d_status;
     b.d_kps = d_kps;
@@ -782,6 +786,8 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
     if (c->timing) {  // stage timing: the whole batch as one group, stages back to back on the caller's stream
         hipEvent_t* ev = &c->events[(size_t)(c->evCount % ORB_EV_RING) * 5];
         c->evCount++;
+        c->lastGroups = orb_quadtree_two_passes(c->geom, n) ? 1 : 0;
+        c->lastGroupFrame0[0] = 0;
         HIP_TRY(hipEventRecord(ev[0], st));
         if ((rc = orb_launch_pyramid(b))) return rc;
         HIP_TRY(hipEventRecord(ev[1], st));
@@ -806,6 +812,9 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
             HIP_TRY(hipStreamWaitEvent(c->aux[i - 1], c->evFork, 0));
         }
     }
+    c->lastGroups = 0;
+    for (int i = 0; i < parts; i++)
+        if (orb_quadtree_two_passes(c->geom, pb[i].nframes)) c->lastGroupFrame0[c->lastGroups++] = pb[i].frame0;
     for (int i = 0; i < parts; i++)
         if ((rc = orb_launch_pyramid(pb[i]))) return rc;
     for (int i = 0; i < parts; i++)
@@ -886,6 +895,24 @@ extern "C" int orb_check_last_batch(orb_ctx* c) {
     const int rc = read_error_flag(c);
     const int rcMatch = orb_match_check_error(c);  // asynchronous matcher calls report through the same function
     return rc ? rc : rcMatch;
+}
+
+extern "C" int orb_quadtree_second_pass_levels(orb_ctx* c, int* levels) {
+    if (!c || !levels) {
+        orb_set_error("orb_quadtree_second_pass_levels: null argument");
+        return ORB_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->prm.device));
+    HIP_TRY(hipDeviceSynchronize());
+    int total = 0;
+    for (int i = 0; i < c->lastGroups; i++) {
+        int n = 0;
+        HIP_TRY(hipMemcpy(&n, (const int*)c->dQtRetry.p + (int64_t)c->lastGroupFrame0[i] * (c->geom.nlevels + 1), sizeof(int),
+                          hipMemcpyDeviceToHost));
+        total += n;
+    }
+    *levels = total;
+    return ORB_OK;
 }
 
 extern "C" int orb_extract_batch_device(orb_ctx* c, const uint8_t* d_imgs, int n, int w, int h, int stride,

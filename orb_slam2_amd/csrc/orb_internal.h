@@ -41,6 +41,7 @@ struct OrbLevel {
     int tabX, tabY;             // first entry of the level's resize taps in the tap table
     int codeTabX, codeTabY;     // first entry of the level's quadtree path words per column / per row (border-relative)
     int histDepth;              // bucket depth (path digits) of the quadtree's histogram form, qt_hist_depth
+    int histDepthFirst;         // ... of the first pass when a batch runs the quadtree in two passes (one digit less)
 };
 
 struct OrbGeom {
@@ -200,6 +201,7 @@ struct OrbBatch {  // everything one extraction launch sequence needs
     int* d_selScore;            // [frame][outCapFrame]
     int* d_levelCount;          // [frame][nlevels] keypoints kept per level
     int* d_levelKeys;           // [frame][nlevels] keys handed to the quadtree (counted by the FAST kernel)
+    int* d_qtRetry;             // quadtree levels handed to the second pass: per frame group a count, then workgroup numbers
     int* d_error;               // flag word, OR of limit bits
     int* d_status;              // optional: per frame, the flag word as the last stage saw it (may be host memory)
     orb_keypoint* d_kps;
@@ -210,6 +212,7 @@ struct OrbBatch {  // everything one extraction launch sequence needs
 };
 
 int orb_launch_pyramid(const OrbBatch& b);
+bool orb_quadtree_two_passes(const OrbGeom& g, int nframes);  // whether orb_launch_quadtree runs such a launch in two passes
 int orb_launch_fast(const OrbBatch& b);
 int orb_launch_quadtree(const OrbBatch& b);
 int orb_launch_describe(const OrbBatch& b);

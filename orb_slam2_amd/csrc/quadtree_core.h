@@ -342,10 +342,10 @@ QT_FN void qt_children(const unsigned long long* s, const OrbNode& nd, int* b, i
 // Bucket depth of the histogram form for a level with nIni initial nodes and quota N: the coarse passes run at
 // least until 4^d nIni >= N (depth dmin) and the fine phase goes one deeper, so dmin + 2 digits cover ordinary
 // images with a level to spare; fewer when that many buckets exceed `bucketCap` (at least one digit).
-static inline int qt_hist_depth(int nIni, int N, int bucketCap) {
+static inline int qt_hist_depth(int nIni, int N, int bucketCap, int margin = 2) {
     int dmin = 0;
     while (((long long)nIni << (2 * dmin)) < N && dmin < ORB_CODE_DEPTH) dmin++;
-    int d = dmin + 2;
+    int d = dmin + margin;
     if (d > ORB_CODE_DEPTH) d = ORB_CODE_DEPTH;
     while (d > 1 && ((long long)nIni << (2 * d)) > bucketCap) d--;
     return d;

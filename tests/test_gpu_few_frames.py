@@ -79,3 +79,40 @@ def test_batch_into_arrays_the_caller_keeps():
             assert cnt[f] == len(ref[f][0])
             assert np.array_equal(kps[f, : cnt[f]], ref[f][0]) and np.array_equal(desc[f, : cnt[f]], ref[f][1])
     ctx.close()
+
+
+def _crowded(w, h, seed):
+    """Flat frame with one textured patch: every keypoint of a level sits in a small part of it, so the quadtree has to
+    divide far below the depth ordinary frames need."""
+    rng = np.random.default_rng(seed)
+    img = np.full((h, w), 128, np.uint8)
+    side = int(rng.integers(90, 180))
+    x0, y0 = int(rng.integers(30, w - side - 30)), int(rng.integers(30, h - side - 30))
+    img[y0 : y0 + side, x0 : x0 + side] = _frame(side, side, seed + 1)
+    return img
+
+
+@pytest.mark.parametrize("quirks", [0x1F, 0x00], ids=["fork", "canonical"])
+def test_quadtree_second_pass_takes_the_crowded_levels(oracle, quirks, monkeypatch):
+    """A large batch runs DistributeOctTree (src/ORBextractor.cc:571-796) in two passes; which pass settles a level
+    must not show in the result.  (The threshold is lowered so that twelve frames count as large.)"""
+    from orb_slam2_amd import binding
+
+    monkeypatch.setenv("ORBHIP_QT_TWO_PASS_MIN", "16")
+    w, h = 640, 480
+    frames = [_crowded(w, h, 500 + 2 * i) for i in range(6)] + [_frame(w, h, 600 + i) for i in range(6)]
+    ctx = binding.Context(1000, 1.2, 8, 20, 7, w, h, 12, 0, quirks)
+    res = ctx.extract_batch(frames)
+    second = ctx.quadtree_second_pass_levels()
+    assert 0 < second < 12 * 8, second  # the crowded frames' levels, not everything
+    one = binding.Context(1000, 1.2, 8, 20, 7, w, h, 1, 0, quirks)
+    for f in range(12):
+        k, d = one.extract(frames[f])  # one pass, full depth
+        assert np.array_equal(k, res[f][0]) and np.array_equal(d, res[f][1]), f
+    assert one.quadtree_second_pass_levels() == 0
+    ext = oracle.Extractor(1000, 1.2, 8, 20, 7, quirks)
+    for f in (0, 3, 7):
+        ko, do = ext.extract(frames[f])
+        assert len(ko) == len(res[f][0]) and (ko == res[f][0]).all() and (do == res[f][1]).all(), f
+    ctx.close()
+    one.close()
