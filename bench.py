@@ -93,19 +93,23 @@ def main():
         local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # ORB_BENCH_FORCE_GROUP=1: a process group (and every collective of the multi-rank path) even for one rank, so
+    # that the RCCL calls can be exercised on a one-GPU box
+    grouped = world > 1 or os.environ.get("ORB_BENCH_FORCE_GROUP") == "1"
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
 
     def max_over_ranks(x):
-        if world == 1:
+        if not grouped:
             return x
         t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -246,7 +250,7 @@ def main():
             last["packed"] = out
             return out
 
-        sbf = ShardedBruteForce(timed_scan, merge)
+        sbf = ShardedBruteForce(timed_scan, merge, always_gather=grouped)
         note("database ready")
         sbf.query(d_q)
         torch.cuda.synchronize()
@@ -463,7 +467,7 @@ def main():
         if rehearse:
             out["rehearsal"] = "ranks share GPUs, gloo collectives: not a measurement"
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

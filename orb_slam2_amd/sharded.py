@@ -46,8 +46,9 @@ class ShardedBruteForce:
     merge(gathered [world, nq]) -> (idx, best, second)
     """
 
-    def __init__(self, scan, merge, group=None):
-        self.scan, self.merge, self.group = scan, merge, group
+    def __init__(self, scan, merge, group=None, always_gather=False):
+        # always_gather: run the collective even in a group of one (exercises the backend on a single device)
+        self.scan, self.merge, self.group, self.always_gather = scan, merge, group, always_gather
 
     def query(self, queries):
         import torch
@@ -55,7 +56,7 @@ class ShardedBruteForce:
 
         packed = self.scan(queries)
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        if world == 1:
+        if world == 1 and not (self.always_gather and dist.is_initialized()):
             gathered = packed.reshape(1, -1)
         else:
             if packed.is_cuda and dist.get_backend(self.group) == "gloo":

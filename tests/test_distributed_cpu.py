@@ -56,7 +56,7 @@ def _worker(rank, world, port, db, q, out):
         gidx = np.where(idx >= 0, idx.astype(np.int64) + lo, 0xFFFFFFFF)
         return torch.from_numpy(pack_top2(b, s, gidx).view(np.int64))
 
-    sb = ShardedBruteForce(scan, merge_rule)
+    sb = ShardedBruteForce(scan, merge_rule, always_gather=(world == 1))  # a group of one still runs the collective
     idx, best, second = sb.query(torch.from_numpy(q))
     if rank == world - 1:  # every rank holds the full answer; check a non-zero rank
         np.save(out, np.stack([idx.astype(np.int64), best.astype(np.int64), second.astype(np.int64)]))
@@ -72,7 +72,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [1, 2, 3])
 def test_sharded_bruteforce_gloo(world, tmp_path, oracle):
     db = synth_descriptors(3001, 31)
     q = synth_queries(db, 200, 32)
