@@ -53,6 +53,17 @@ def one(it, seed):
             ok = False
         res.append((ko, do))
     (k1, d1), (k2, d2) = res
+    if ok and it % 3 == 0:
+        # the batch paths (a launch per pyramid level, frame groups, the quadtree's two passes) on the same geometry:
+        # nine frames in one call must give what the one-frame calls gave
+        cb = binding.Context(nf, sf, nl, ini, mn, w, h, 9, 0, preset)
+        out = cb.extract_batch([a, b, a, b, b, a, a, b, a])
+        for f, (kb, db_) in enumerate(out):
+            ko, do = res[0] if f in (0, 2, 5, 6, 8) else res[1]
+            if len(kb) != len(ko) or not (kb == ko).all() or not (db_ == do).all():
+                print(tag, "BATCH MISMATCH frame", f)
+                ok = False
+        cb.close()
     if ok and len(k1) and len(k2) and len(k2) <= 8192:
         prev0 = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32)
         win = int(r[13] % np.uint64(150)) + 5
