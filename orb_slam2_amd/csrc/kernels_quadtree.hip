@@ -366,7 +366,9 @@ static QtLaunch qt_plan(const OrbGeom& g, bool bigFrames, int pass) {
 
 static int qt_launch(const OrbBatch& b, bool bigFrames, int pass) {
     const OrbGeom& g = *b.h_geom;
-    const int threads = bigFrames ? 1024 : 256;
+    // (a few frames: twice the threads shorten the counting pass of the one workgroup everything waits for,
+    // level 0's, 39 -> 35 us; four times gain nothing more)
+    const int threads = bigFrames ? 1024 : (b.nframes < ORB_FEW_FRAMES ? 512 : 256);
     QtLaunch q = qt_plan(g, bigFrames, pass);
     q.nframesMagic = orb_div_magic((uint32_t)b.nframes, (uint64_t)b.nframes * q.nlevels);
     const size_t lds = (size_t)q.ldsKeys * 8 + (size_t)q.regionInts * 4;
