@@ -53,3 +53,10 @@ def test_dropin_cpp_compiles():
     src = [os.path.join(ROOT, "orb_slam2_amd", "cpp", f) for f in ("ORBextractor.cc", "Frame.cc", "ORBmatcher.cc")]
     src.append(os.path.join(ROOT, "examples", "orb_demo.cc"))
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror"] + src)
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: the header must be usable from a C translation unit."""
+    src = tmp_path / "use.c"
+    src.write_text('#include "orb_hip.h"\nint use(orb_ctx* c) { int n = 0; return orb_quadtree_second_pass_levels(c, &n) + n; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src)])
