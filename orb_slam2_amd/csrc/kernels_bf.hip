@@ -1,24 +1,13 @@
 // Brute-force Hamming top-2 over a descriptor database shard for gfx950.
 //
-// The unit of work is ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:460-476):
-// popcount of a 256-bit XOR, i.e. 8 x (v_xor_b32 + accumulating v_bcnt_u32_b32).
-// The scan applies the best / second-best rule of src/ORBmatcher.cc:53-76 to
-// every database row in index order.
-//
-// Mapping: one lane holds QPL query descriptors in registers (8 VGPRs each).
-// A workgroup copies TR database rows per tile into LDS with one coalesced
-// 16-byte load per thread (two tiles in flight) and every wavefront reads the
-// rows back as broadcast ds_read_b128 (all lanes the same address, no bank
-// conflict), so a comparison is VGPR x VGPR and the row traffic rides the
-// vector memory path.  (Rows streamed through scalar loads instead stall on the
-// scalar data cache, which sustains about one 64-byte miss per ~130 cycles per
-// CU.)  Rows are taken GROUP at a time; the top-2 state (best distance, best
-// row, second distance per query) is only touched when some lane of the wave
-// saw a distance below its current second best, which for all but the first few
-// thousand rows of a chunk is rare.  The database is cut into chunks along
-// blockIdx.y so that a shard fills the chip; per-chunk results are packed as
-// best << 48 | second << 32 | global row and combined by the same merge kernel
-// that combines the shards of several GPUs.
+// The unit of work is ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:460-476), the popcount of a 256-bit XOR, and
+// the scan applies the best / second-best rule of src/ORBmatcher.cc:53-76 to every database row in index order.
+// All pairs of (query, row) with a 256-term sum each is a matrix product, so the distances are made on the matrix
+// cores (k_bf_mfma below: bits as +-1 / 0-1 bytes, v_mfma_i32_32x32x32_i8), and only the top-2 bookkeeping runs on
+// the vector ALU.  The database is cut into chunks along blockIdx.y so that a shard fills the chip; per-chunk
+// results are packed as best << 48 | second << 32 | global row and combined by the same merge kernel that combines
+// the shards of several GPUs.  (The vector-ALU form of the scan, 8 x (v_xor_b32 + v_bcnt_u32_b32) per comparison at
+// 0.88 of that pair's measured issue ceiling, is kept under tools/ for reference: the matrix form is twice as fast.)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -77,201 +66,157 @@ static int bf_static_block(int device, unsigned long long** out) {
 }
 
 
-struct Row256 {  // one database row, the same for every lane of the wavefront
-    uint4 lo, hi;
-};
+// ---- the scan: all-pairs Hamming distances on the matrix cores ------------------------------------------------
+// Query bits become bytes +1 (set) / -1 (clear), database bits bytes 1 / 0.  The dot product of a row and a query is
+// then (bits set in both) - (bits set in the row only) = popcount(query) - distance, so per query the largest
+// product is the nearest row, and v_mfma_i32_32x32x32_i8 makes 32 rows x 32 queries x 32 bits of it per instruction
+// (1024 multiply-adds per cycle and SIMD against 16 lanes of xor / bcnt on the vector ALU).
+//
+// A wavefront keeps BFM_QB blocks of 32 queries as B operands in registers for the whole scan (lane (c, h) holds bits
+// [32 ks + 16 h, + 16) of query c for the eight k-steps ks; the A operand below uses the same bit order, which is all
+// the products need).  The workgroup's four wavefronts share the database rows: 256 threads fetch a tile of BFM_TR
+// rows as bits (8 bytes per thread), expand them to bytes in LDS (a 24-bit multiply spreads a nibble's bits over
+// four bytes), two tiles in flight, and every wavefront reads its A operands from there with ds_read_b128.  The
+// 32 x 32 products of a (row block, query block) arrive with the query on the lane and 16 rows in 16 registers
+// (row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)): a lane keeps the top-2 of one query over its rows — the maximum
+// of the 16 against the query's second best decides whether the registers are looked at one by one, which is rare
+// after the first rows of a chunk — and the two lanes of a query report separately: the merge kernel combines them
+// like two chunks.  Chunks along blockIdx.y as before.
+typedef int bfm_v4i __attribute__((ext_vector_type(4)));
+typedef int bfm_v16i __attribute__((ext_vector_type(16)));
+#define BFM_QB 4      // blocks of 32 queries per wavefront: 512 queries per workgroup
+#define BFM_TR 64     // database rows per tile
+#define BFM_ROWP 272  // bytes per expanded row in LDS (256 + 16: consecutive rows start 16 bytes apart in the banks)
+#define BFM_LDS (2 * BFM_TR * BFM_ROWP)
+#define BFM_QUERIES_PER_WG (4 * BFM_QB * 32)
+#define BFM_NONE (-100000)  // below any product
 
-static __device__ __forceinline__ Row256 load_row(const uint32_t* __restrict__ p) {
-    Row256 r;
-    r.lo = ((const uint4*)p)[0];
-    r.hi = ((const uint4*)p)[1];
-    return r;
-}
-
-// popcount of the 256-bit XOR of a query (a) and a row (r): 8 x (v_xor_b32 + accumulating v_bcnt_u32_b32).
-// One asm statement, for two reasons.  The compiler otherwise splits the accumulation into bcnt(x, 0) plus
-// separate adds.  And the scalar no-op between a v_xor and the v_bcnt that reads its result matters: v_xor_b32
-// is a double-rate instruction on gfx950 (a wavefront's 64 lanes in about 2 cycles), v_bcnt_u32_b32 a
-// single-rate one (4 cycles), yet a wavefront that issues the v_bcnt straight after the v_xor costs the SIMD
-// about 7.8 cycles per pair, whatever the distance between the two; with one scalar instruction after the
-// v_xor the pair takes about 6.6, and a further one after the v_bcnt makes it 8.3 (tools/valu_peak.hip measures
-// these orders).  Between separate asm statements the compiler adds such a no-op of its own, hence one statement.
-// PATTERN selects the order (a tuning parameter; the product uses BF_PATTERN): 0 = no scalar instruction,
-// 1 = s_nop 0 after every v_xor, 2 = s_nop 1 after every v_xor, 3 = every v_xor issued one pair ahead of
-// the v_bcnt that reads it, s_nop 0 between.
-#define BF_X(k, K) "v_xor_b32 %1, %" #k ", %" #K "\n\t"
-#define BF_X2(k, K) "v_xor_b32 %2, %" #k ", %" #K "\n\t"
-#define BF_B0 "v_bcnt_u32_b32 %0, %1, 0\n\t"
-#define BF_B "v_bcnt_u32_b32 %0, %1, %0\n\t"
-#define BF_B2 "v_bcnt_u32_b32 %0, %2, %0\n\t"
-#define BF_N0 "s_nop 0\n\t"
-#define BF_N1 "s_nop 1\n\t"
-#define BF_INS(a, r)                                                                                                  \
-    "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(r.lo.x), "v"(r.lo.y), \
-        "v"(r.lo.z), "v"(r.lo.w), "v"(r.hi.x), "v"(r.hi.y), "v"(r.hi.z), "v"(r.hi.w)
-template <int PATTERN>
-static __device__ __forceinline__ uint32_t hamming256(const uint32_t (&a)[8], const Row256& r) {
-    uint32_t d, t, u;
-    if (PATTERN == 0) {
-        asm(BF_X(3, 11) BF_B0 BF_X(4, 12) BF_B BF_X(5, 13) BF_B BF_X(6, 14) BF_B BF_X(7, 15) BF_B BF_X(8, 16) BF_B BF_X(9, 17)
-                BF_B BF_X(10, 18) BF_B
-            : "=&v"(d), "=&v"(t), "=&v"(u)
-            : BF_INS(a, r));
-    } else if (PATTERN == 1) {
-        asm(BF_X(3, 11) BF_N0 BF_B0 BF_X(4, 12) BF_N0 BF_B BF_X(5, 13) BF_N0 BF_B BF_X(6, 14) BF_N0 BF_B BF_X(7, 15) BF_N0 BF_B
-                BF_X(8, 16) BF_N0 BF_B BF_X(9, 17) BF_N0 BF_B BF_X(10, 18) BF_N0 BF_B
-            : "=&v"(d), "=&v"(t), "=&v"(u)
-            : BF_INS(a, r));
-    } else if (PATTERN == 2) {
-        asm(BF_X(3, 11) BF_N1 BF_B0 BF_X(4, 12) BF_N1 BF_B BF_X(5, 13) BF_N1 BF_B BF_X(6, 14) BF_N1 BF_B BF_X(7, 15) BF_N1 BF_B
-                BF_X(8, 16) BF_N1 BF_B BF_X(9, 17) BF_N1 BF_B BF_X(10, 18) BF_N1 BF_B
-            : "=&v"(d), "=&v"(t), "=&v"(u)
-            : BF_INS(a, r));
-    } else {
-        asm(BF_X(3, 11) BF_X2(4, 12) BF_N0 BF_B0 BF_X(5, 13) BF_N0 BF_B2 BF_X2(6, 14) BF_N0 BF_B BF_X(7, 15) BF_N0 BF_B2
-                BF_X2(8, 16) BF_N0 BF_B BF_X(9, 17) BF_N0 BF_B2 BF_X2(10, 18) BF_N0 BF_B BF_N0 BF_B2
-            : "=&v"(d), "=&v"(t), "=&v"(u)
-            : BF_INS(a, r));
-    }
-    return d;
-}
-
-static __device__ __forceinline__ void top2_update(uint32_t d, uint32_t row, uint32_t& bd, uint32_t& bi, uint32_t& sd) {
-    // strict '<' in scan order: an equal distance never replaces the best, but becomes the second best
-    if (d < sd) {
-        if (d < bd) {
-            sd = bd;
-            bd = d;
-            bi = row;
-        } else {
-            sd = d;
+// 16 descriptor bits -> 16 bytes
+template <bool QUERY>
+static __device__ __forceinline__ bfm_v4i bfm_expand16(uint32_t bits) {
+    bfm_v4i o;
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        const uint32_t nib = (bits >> (4 * n)) & 15u;
+        uint32_t m = __umul24(nib, 0x00204081u) & 0x01010101u;  // bit i of the nibble -> bit 0 of byte i
+        if (QUERY) {
+            m ^= 0x01010101u;                  // 1 where the bit is clear
+            m = ((m << 8) - m) | 0x01010101u;  // 0xFF there, 0x01 where it is set
         }
+        o[n] = (int)m;
     }
+    return o;
 }
 
-// One group of GROUP rows against the lane's QPL queries.
-template <int QPL, int GROUP, int PATTERN>
-static __device__ __forceinline__ void bf_group(const uint32_t (&qv)[QPL][8], const Row256 (&rw)[GROUP], uint32_t rowBase,
-                                                uint32_t (&bd)[QPL], uint32_t (&bi)[QPL], uint32_t (&sd)[QPL]) {
-    uint32_t d[GROUP][QPL];
-    bool any = false;
-#pragma unroll
-    for (int g = 0; g < GROUP; g++) {
-#pragma unroll
-        for (int j = 0; j < QPL; j++) {
-            d[g][j] = hamming256<PATTERN>(qv[j], rw[g]);
-        }
-    }
-    // one compare per query against the smallest distance of the group
-#pragma unroll
-    for (int j = 0; j < QPL; j++) {
-        uint32_t m = d[0][j];
-#pragma unroll
-        for (int g = 1; g < GROUP; g++) m = min(m, d[g][j]);
-        any |= m < sd[j];
-    }
-    if (__builtin_amdgcn_ballot_w64(any)) {
-#pragma unroll
-        for (int g = 0; g < GROUP; g++) {
-#pragma unroll
-            for (int j = 0; j < QPL; j++) top2_update(d[g][j], rowBase + g, bd[j], bi[j], sd[j]);
-        }
-    }
-}
-
-template <int QPL, int GROUP, int TR, int PATTERN>
-__global__ __launch_bounds__(256) void k_bf_top2_lds(const uint32_t* __restrict__ q, int nq,
-                                                     const uint32_t* __restrict__ db, long long nd,
-                                                     long long rowsPerChunk, long long globalBase,
-                                                     unsigned long long* __restrict__ partial) {
-    static_assert(TR * 32 % (256 * 16) == 0, "tile must be a whole number of 16-byte loads per thread");
-    constexpr int LPT = TR * 32 / (256 * 16);  // 16-byte loads per thread and tile
-    __shared__ __attribute__((aligned(16))) uint32_t s_rows[2][TR * 8];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    long long qb = ((long long)blockIdx.x * 4 + wave) * (64 * QPL);
-    const bool active = qb < nq;   // inactive waves still help loading tiles and hit every barrier
-    if (!active) qb = 0;
-    uint32_t qv[QPL][8];
-    uint32_t bd[QPL], sd[QPL], bi[QPL];
-#pragma unroll
-    for (int j = 0; j < QPL; j++) {
-        long long qi = qb + j * 64 + lane;
-        if (qi >= nq) qi = nq - 1;
-        const uint4* p = (const uint4*)(q + qi * 8);
-        const uint4 lo = p[0], hi = p[1];
-        qv[j][0] = lo.x; qv[j][1] = lo.y; qv[j][2] = lo.z; qv[j][3] = lo.w;
-        qv[j][4] = hi.x; qv[j][5] = hi.y; qv[j][6] = hi.z; qv[j][7] = hi.w;
-        bd[j] = BF_NONE;
-        sd[j] = BF_NONE;
-        bi[j] = 0xFFFFFFFFu;
-    }
+__global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__ q, int nq, const uint32_t* __restrict__ db,
+                                                    long long n, long long rowsPerChunk, long long globalBase,
+                                                    unsigned long long* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_rows[];  // two buffers of BFM_TR expanded rows
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, h = lane >> 5, c = lane & 31;
+    const long long q0 = (long long)blockIdx.x * BFM_QUERIES_PER_WG + w * (BFM_QB * 32);
     const long long r0 = (long long)blockIdx.y * rowsPerChunk;
-    const long long r1 = (r0 + rowsPerChunk < nd) ? r0 + rowsPerChunk : nd;
-    const long long lastByte = nd * 32 - 16;  // clamp tile loads that run past the database
-    const uint8_t* dbb = (const uint8_t*)db;
-    uint4 stage[LPT];
-    auto fetch = [&](long long tileRow) {
+    const long long rEnd = r0 + rowsPerChunk < n ? r0 + rowsPerChunk : n;
+    const int rows = (int)(rEnd - r0);
+    if (rows <= 0) return;  // (the whole workgroup; the launcher makes no such chunk)
+
+    bfm_v4i bq[BFM_QB][8];
+    int pcq[BFM_QB];  // popcount of the lane's queries: distance = popcount - product
 #pragma unroll
-        for (int k = 0; k < LPT; k++) {
-            long long off = tileRow * 32 + ((long long)k * 256 + threadIdx.x) * 16;
-            if (off > lastByte) off = lastByte;
-            stage[k] = *(const uint4*)(dbb + off);
+    for (int b = 0; b < BFM_QB; b++) {
+        const long long qi = q0 + b * 32 + c;
+        pcq[b] = 0;
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+            const uint32_t word = qi < nq ? q[qi * 8 + ks] : 0u;
+            pcq[b] += __popc(word);
+            bq[b][ks] = bfm_expand16<true>(h ? word >> 16 : word & 0xffffu);
         }
-    };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int k = 0; k < LPT; k++) ((uint4*)s_rows[buf])[k * 256 + threadIdx.x] = stage[k];
-    };
-    if (r0 < r1) {
-        fetch(r0);
-        stash(0);
     }
+    int best[BFM_QB], sec[BFM_QB], bidx[BFM_QB];
+#pragma unroll
+    for (int b = 0; b < BFM_QB; b++) best[b] = sec[b] = BFM_NONE, bidx[b] = 0;
+
+    // staging: thread = (row t / 4, word pair t % 4) of a tile
+    static_assert(BFM_TR == 64, "one row quarter per thread");
+    const int srow = t >> 2, swp = t & 3;
+    auto fetch = [&](int tile) -> uint2 {
+        const long long r = r0 + (long long)tile * BFM_TR + srow;
+        return r < rEnd ? *(const uint2*)(db + r * 8 + 2 * swp) : uint2{0u, 0u};  // (rows past the end: no bit set,
+    };                                                                              // and rejected by number below)
+    auto stash = [&](int buf, uint2 wds) {
+        uint8_t* d = s_rows + buf * (BFM_TR * BFM_ROWP) + srow * BFM_ROWP + swp * 64;
+        *(bfm_v4i*)(d + 0) = bfm_expand16<false>(wds.x & 0xffffu);
+        *(bfm_v4i*)(d + 16) = bfm_expand16<false>(wds.x >> 16);
+        *(bfm_v4i*)(d + 32) = bfm_expand16<false>(wds.y & 0xffffu);
+        *(bfm_v4i*)(d + 48) = bfm_expand16<false>(wds.y >> 16);
+    };
+    const int ntiles = (rows + BFM_TR - 1) / BFM_TR;
+    stash(0, fetch(0));
     __syncthreads();
-    int buf = 0;
-    for (long long t = r0; t < r1; t += TR) {
-        const bool more = t + TR < r1;
-        if (more) fetch(t + TR);
-        const int rowsHere = (int)((r1 - t < TR) ? r1 - t : TR);
-        if (active) {
-            const uint32_t* tile = s_rows[buf];
-            int r = 0;
-            for (; r + GROUP <= rowsHere; r += GROUP) {
-                Row256 rw[GROUP];
+    for (int tile = 0; tile < ntiles; tile++) {
+        const int buf = tile & 1;
+        const bool more = tile + 1 < ntiles;
+        uint2 nextw = {0u, 0u};
+        if (more) nextw = fetch(tile + 1);
+        const uint8_t* base = s_rows + buf * (BFM_TR * BFM_ROWP) + c * BFM_ROWP + h * 16;
 #pragma unroll
-                for (int g = 0; g < GROUP; g++) rw[g] = load_row(tile + (r + g) * 8);
-                bf_group<QPL, GROUP, PATTERN>(qv, rw, (uint32_t)(t - r0) + r, bd, bi, sd);
+        for (int rb = 0; rb < BFM_TR / 32; rb++) {
+            bfm_v16i acc[BFM_QB];
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) {
+                const bfm_v4i a = *(const bfm_v4i*)(base + rb * 32 * BFM_ROWP + ks * 32);
+#pragma unroll
+                for (int b = 0; b < BFM_QB; b++) {
+                    if (ks == 0) {
+                        const bfm_v16i zero = {};
+                        acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[b][ks], zero, 0, 0, 0);
+                    } else {
+                        acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[b][ks], acc[b], 0, 0, 0);
+                    }
+                }
             }
-            for (; r < rowsHere; r++) {
-                const Row256 row = load_row(tile + r * 8);
+            const int rowBase = tile * BFM_TR + rb * 32 + 4 * h;
 #pragma unroll
-                for (int j = 0; j < QPL; j++)
-                    top2_update(hamming256<PATTERN>(qv[j], row), (uint32_t)(t - r0) + r, bd[j], bi[j], sd[j]);
+            for (int b = 0; b < BFM_QB; b++) {
+                const bfm_v16i s = acc[b];
+                int m = max(max(max(s[0], s[1]), max(s[2], s[3])), max(max(s[4], s[5]), max(s[6], s[7])));
+                m = max(m, max(max(max(s[8], s[9]), max(s[10], s[11])), max(max(s[12], s[13]), max(s[14], s[15]))));
+                if (__ballot(m > sec[b]) != 0ull) {
+                    // rows in ascending order: on equal products the earlier row stays the best, as in a scan
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int r = rowBase + (i & 3) + 8 * (i >> 2);
+                        const int v = s[i];
+                        if (r < rows && v > sec[b]) {
+                            if (v > best[b]) {
+                                sec[b] = best[b];
+                                best[b] = v;
+                                bidx[b] = r;
+                            } else {
+                                sec[b] = v;
+                            }
+                        }
+                    }
+                }
             }
         }
-        if (more) stash(buf ^ 1);
+        if (more) stash(buf ^ 1, nextw);
         __syncthreads();
-        buf ^= 1;
     }
-    if (!active) return;
 #pragma unroll
-    for (int j = 0; j < QPL; j++) {
-        const long long qi = qb + j * 64 + lane;
+    for (int b = 0; b < BFM_QB; b++) {
+        const long long qi = q0 + b * 32 + c;
         if (qi < nq) {
+            const unsigned long long bd = best[b] == BFM_NONE ? (unsigned long long)BF_NONE : (unsigned long long)(pcq[b] - best[b]);
+            const unsigned long long sd = sec[b] == BFM_NONE ? (unsigned long long)BF_NONE : (unsigned long long)(pcq[b] - sec[b]);
             const unsigned long long idx =
-                (bd[j] == BF_NONE) ? 0xFFFFFFFFull : (unsigned long long)(globalBase + r0 + bi[j]) & 0xFFFFFFFFull;
-            partial[(long long)blockIdx.y * nq + qi] =
-                ((unsigned long long)bd[j] << 48) | ((unsigned long long)sd[j] << 32) | idx;
+                best[b] == BFM_NONE ? 0xFFFFFFFFull : (unsigned long long)(globalBase + r0 + bidx[b]) & 0xFFFFFFFFull;
+            partial[((long long)blockIdx.y * 2 + h) * nq + qi] = (bd << 48) | (sd << 32) | idx;
         }
     }
 }
+#define BF_PARTS_PER_CHUNK 2  // partial words per (chunk, query): one per half of the wavefront
 
-// Tuning of the scan kernel (measured over 2..8 queries per lane, groups of 2..8 rows, tiles of 128 / 256 rows).
-#define BF_QPL 2
-#define BF_GROUP 4
-#define BF_TILE_ROWS 128
-#define BF_PATTERN 1
-typedef void (*bf_kernel_t)(const uint32_t*, int, const uint32_t*, long long, long long, long long, unsigned long long*);
-static const bf_kernel_t k_bf_scan = k_bf_top2_lds<BF_QPL, BF_GROUP, BF_TILE_ROWS, BF_PATTERN>;
 
 // Combine nshards packed candidates per query.  Inserting every shard's best
 // (distance, row) and second distance into one running top-2 equals scanning
@@ -322,7 +267,7 @@ extern "C" int orb_bf_create(int device, orb_bf** out) {
     int rc = bf_static_block(device, &block);
     if (rc) return rc;
     int perCu = 0, cus = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_bf_scan, 256, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_bf_mfma, 256, BFM_LDS));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
     hipStream_t st = nullptr;
     HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -416,9 +361,9 @@ extern "C" int orb_bf_set_database(orb_bf* bf, const uint8_t* db, int64_t n, int
 // so that the last round is (almost) full instead of leaving most of the chip
 // idle behind a few stragglers, while chunks stay long enough that the first
 // rows of a chunk (which update the top-2 state often) are a small share.
-static int bf_chunks(int nq, int64_t nd, int resident, int qpl, int group, long long chunkLimit,
+static int bf_chunks(int nq, int64_t nd, int resident, int queriesPerWg, int group, long long chunkLimit,
                      long long* rowsPerChunk) {
-    const long long qBlocks = (nq + 256 * qpl - 1) / (256 * qpl);
+    const long long qBlocks = (nq + queriesPerWg - 1) / queriesPerWg;
     const long long maxChunks = std::max<long long>(1, std::min<long long>(std::min<long long>(nd / 8192, 4096), chunkLimit));
     long long best = 1;
     double bestEff = -1.0;
@@ -445,14 +390,16 @@ static int bf_chunks(int nq, int64_t nd, int resident, int qpl, int group, long 
 // Scan + per-chunk merge into d_packed, partials in `partial` (room for chunkLimit * nq words).
 static int bf_scan_into(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t* d_packed, unsigned long long* partial,
                         int chunks, long long rpc, hipStream_t st) {
-    const int qBlocks = (nq + 256 * BF_QPL - 1) / (256 * BF_QPL);
+    const int qBlocks = (nq + BFM_QUERIES_PER_WG - 1) / BFM_QUERIES_PER_WG;
+    int parts = BF_PARTS_PER_CHUNK * chunks;
     if (bf->n > 0) {
-        hipLaunchKernelGGL(k_bf_scan, dim3(qBlocks, chunks), dim3(256), 0, st, (const uint32_t*)d_q, nq,
+        hipLaunchKernelGGL(k_bf_mfma, dim3(qBlocks, chunks), dim3(256), BFM_LDS, st, (const uint32_t*)d_q, nq,
                            (const uint32_t*)bf->d_db, (long long)bf->n, rpc, (long long)bf->globalBase, partial);
     } else {
         HIP_TRY(hipMemsetAsync(partial, 0xFF, (size_t)nq * 8, st));
+        parts = 1;
     }
-    hipLaunchKernelGGL(k_bf_merge, dim3((nq + 255) / 256), dim3(256), 0, st, (const unsigned long long*)partial, chunks,
+    hipLaunchKernelGGL(k_bf_merge, dim3((nq + 255) / 256), dim3(256), 0, st, (const unsigned long long*)partial, parts,
                        nq, (unsigned long long*)d_packed, (int32_t*)nullptr, (uint16_t*)nullptr, (uint16_t*)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -469,9 +416,9 @@ extern "C" int orb_bf_query_packed_device(orb_bf* bf, const uint8_t* d_q, int nq
     }
     if (nq == 0) return ORB_OK;
     HIP_TRY(hipSetDevice(bf->device));
-    long long rpc = BF_GROUP;
-    const int chunks = bf_chunks(nq, bf->n, bf->residentBlocks, BF_QPL, BF_GROUP, 4096, &rpc);
-    int rc = bf_ensure(bf->d_partial, bf->partialBytes, (size_t)chunks * nq * 8);
+    long long rpc = BFM_TR;
+    const int chunks = bf_chunks(nq, bf->n, bf->residentBlocks, BFM_QUERIES_PER_WG, BFM_TR, 4096, &rpc);
+    int rc = bf_ensure(bf->d_partial, bf->partialBytes, (size_t)BF_PARTS_PER_CHUNK * chunks * nq * 8);
     if (rc) return rc;
     return bf_scan_into(bf, d_q, nq, d_packed, (unsigned long long*)bf->d_partial, chunks, rpc, (hipStream_t)stream);
 }
@@ -488,9 +435,10 @@ extern "C" int orb_bf_query_packed_noalloc(orb_bf* bf, const uint8_t* d_q, int n
     }
     if (nq == 0) return ORB_OK;
     HIP_TRY(hipSetDevice(bf->device));
-    // as many chunks as the fixed block has room for: ORB_BF_NOALLOC_MAX_QUERIES queries still get 16
-    long long rpc = BF_GROUP;
-    const int chunks = bf_chunks(nq, bf->n, bf->residentBlocks, BF_QPL, BF_GROUP, (long long)(BF_STATIC_WORDS / (unsigned)nq), &rpc);
+    // as many chunks as the fixed block has room for: ORB_BF_NOALLOC_MAX_QUERIES queries still get 8
+    long long rpc = BFM_TR;
+    const int chunks = bf_chunks(nq, bf->n, bf->residentBlocks, BFM_QUERIES_PER_WG, BFM_TR,
+                                 (long long)(BF_STATIC_WORDS / BF_PARTS_PER_CHUNK / (unsigned)nq), &rpc);
     // every (chunk, query) word is written by the scan before the merge reads it: nothing to clear between calls
     return bf_scan_into(bf, d_q, nq, d_packed, bf->d_static, chunks, rpc, (hipStream_t)stream);
 }

@@ -7,6 +7,7 @@
 #include <cstdio>
 
 #include "../orb_slam2_amd/csrc/kernels_bf.hip"
+#include "bf_valu_scan.inc"
 
 void orb_set_error(const char* fmt, ...) {
     va_list ap;
@@ -41,7 +42,7 @@ static void run(const char* name) {
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_bf_top2_lds<QPL, GROUP, TR, PATTERN>, 256, 0);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
     long long rpc = GROUP;
-    const int chunks = bf_chunks(nq, nd, perCu * cus, QPL, GROUP, 4096, &rpc);
+    const int chunks = bf_chunks(nq, nd, perCu * cus, 256 * QPL, GROUP, 4096, &rpc);
     const int qBlocks = (nq + 256 * QPL - 1) / (256 * QPL);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
