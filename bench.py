@@ -38,9 +38,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, spec
 # best = 21.3 lanes per clock = 52.4 T lane-ops/s; the best order of the bare pair the micro-benchmark found
 # sustains 49.4 T (20.1 lanes per clock).  That measured figure is the peak the scan kernel is priced against.
 VALU_LANE_OPS = 49.4e12
-# The scan now makes the distances on the matrix cores (one comparison = 256 int8 multiply-adds); its ceiling is the
-# dense int8 MFMA rate: v_mfma_i32_32x32x32_i8 = 32768 multiply-adds per 32 cycles and SIMD, 1024 SIMDs, 2.4 GHz.
-MFMA_I8_OPS = 1024 * 2.4e9 * 2048
+# The scan makes the distances on the matrix cores (one comparison = 256 multiply-adds on FP4 operands holding the
+# values 0 and +-1); its ceiling is the dense FP4 MFMA rate: v_mfma_scale_f32_32x32x64_f8f6f4 = 65536 multiply-adds
+# per 32 cycles and SIMD, 1024 SIMDs, 2.4 GHz (about 10 PFLOP/s).
+MFMA_FP4_OPS = 1024 * 2.4e9 * 4096
 VALU_LANE_OPS_SINGLE_RATE = 256 * 4 * 16 * 2.4e9   # what both instructions would give at 16 lanes per clock
 
 
@@ -275,9 +276,10 @@ def main():
             "queries": nq, "db_rows": nd, "rows_per_rank": hi - lo, "steps": args.bf_steps, "scaling": "strong",
             "ms_per_step": round(dth / args.bf_steps * 1e3, 3),
             "roofline": {"bound": "mfma", "kernel": "k_bf_mfma", "achieved": round(kern_gcmp * 1e9 * 512 / 1e12, 1),
-                         "peak": round(MFMA_I8_OPS / 1e12, 1), "unit": "TOP/s",
-                         "frac": round(kern_gcmp * 1e9 * 512 / MFMA_I8_OPS, 4),
-                         "peak_source": "dense int8 MFMA: 2048 operations per cycle and SIMD x 1024 SIMDs x 2.4 GHz; a comparison is 256 multiply-adds",
+                         "peak": round(MFMA_FP4_OPS / 1e12, 1), "unit": "TOP/s",
+                         "frac": round(kern_gcmp * 1e9 * 512 / MFMA_FP4_OPS, 4),
+                         "peak_source": "dense FP4 MFMA: 4096 operations per cycle and SIMD x 1024 SIMDs x 2.4 GHz; a comparison is 256 multiply-adds",
+                         "int8_form_gcmp_per_s": 6204,
                          "vector_alu_form": {"what": "the same scan as 8 x (v_xor_b32 + v_bcnt_u32_b32) per comparison, the library's kernel until this one (tools/bf_valu_scan.inc)",
                                              "gcmp_per_s": 2734, "ceiling_gcmp_per_s": round(VALU_LANE_OPS / 16 / 1e9),
                                              "this_kernel_over_its_ceiling": round(lane_ops / VALU_LANE_OPS, 3)},

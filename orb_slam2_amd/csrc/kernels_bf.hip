@@ -3,11 +3,11 @@
 // The unit of work is ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:460-476), the popcount of a 256-bit XOR, and
 // the scan applies the best / second-best rule of src/ORBmatcher.cc:53-76 to every database row in index order.
 // All pairs of (query, row) with a 256-term sum each is a matrix product, so the distances are made on the matrix
-// cores (k_bf_mfma below: bits as +-1 / 0-1 bytes, v_mfma_i32_32x32x32_i8), and only the top-2 bookkeeping runs on
+// cores (k_bf_mfma below: bits as the FP4 values +-1 / 0-1, v_mfma_scale_f32_32x32x64_f8f6f4), and only the top-2 bookkeeping runs on
 // the vector ALU.  The database is cut into chunks along blockIdx.y so that a shard fills the chip; per-chunk
 // results are packed as best << 48 | second << 32 | global row and combined by the same merge kernel that combines
 // the shards of several GPUs.  (The vector-ALU form of the scan, 8 x (v_xor_b32 + v_bcnt_u32_b32) per comparison at
-// 0.88 of that pair's measured issue ceiling, is kept under tools/ for reference: the matrix form is twice as fast.)
+// 0.88 of that pair's measured issue ceiling, is kept under tools/ for reference: the matrix form is 3.4 times as fast.)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -67,42 +67,46 @@ static int bf_static_block(int device, unsigned long long** out) {
 
 
 // ---- the scan: all-pairs Hamming distances on the matrix cores ------------------------------------------------
-// Query bits become bytes +1 (set) / -1 (clear), database bits bytes 1 / 0.  The dot product of a row and a query is
+// Query bits become the values +1 (set) / -1 (clear), database bits 1 / 0.  The dot product of a row and a query is
 // then (bits set in both) - (bits set in the row only) = popcount(query) - distance, so per query the largest
-// product is the nearest row, and v_mfma_i32_32x32x32_i8 makes 32 rows x 32 queries x 32 bits of it per instruction
-// (1024 multiply-adds per cycle and SIMD against 16 lanes of xor / bcnt on the vector ALU).
+// product is the nearest row.  The values are held as FP4 (E2M1: 0x0 = 0, 0x2 = 1, 0xA = -1; block scales 2^0), the
+// narrowest operand type of the matrix cores, and v_mfma_scale_f32_32x32x64_f8f6f4 makes 32 rows x 32 queries x 64
+// bits per instruction into f32 accumulators — sums of at most 256 terms of magnitude 1, exact in any order.
+// (As int8 with v_mfma_i32_32x32x32_i8 the scan ran at 6.2 k Gcmp/s, as FP4 at 9.2 k; on the vector ALU at 2.7 k.)
 //
-// A wavefront keeps BFM_QB blocks of 32 queries as B operands in registers for the whole scan (lane (c, h) holds bits
-// [32 ks + 16 h, + 16) of query c for the eight k-steps ks; the A operand below uses the same bit order, which is all
-// the products need).  The workgroup's four wavefronts share the database rows: 256 threads fetch a tile of BFM_TR
-// rows as bits (8 bytes per thread), expand them to bytes in LDS (a 24-bit multiply spreads a nibble's bits over
-// four bytes), two tiles in flight, and every wavefront reads its A operands from there with ds_read_b128.  The
+// A wavefront keeps BFM_QB blocks of 32 queries as B operands in registers for the whole scan (lane (c, h) holds word
+// 2 ks + h of query c for the four k-steps ks; the A operand below uses the same bit order, which is all the
+// products need).  The workgroup's four wavefronts share the database rows: 256 threads fetch a tile of BFM_TR rows
+// as bits (8 bytes per thread), expand them to FP4 in LDS (three shift-or / mask steps spread a byte's bits over
+// eight nibbles), two tiles in flight, and every wavefront reads its A operands from there with ds_read_b128.  The
 // 32 x 32 products of a (row block, query block) arrive with the query on the lane and 16 rows in 16 registers
 // (row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)): a lane keeps the top-2 of one query over its rows — the maximum
 // of the 16 against the query's second best decides whether the registers are looked at one by one, which is rare
 // after the first rows of a chunk — and the two lanes of a query report separately: the merge kernel combines them
 // like two chunks.  Chunks along blockIdx.y as before.
 typedef int bfm_v4i __attribute__((ext_vector_type(4)));
-typedef int bfm_v16i __attribute__((ext_vector_type(16)));
+typedef int bfm_v8i __attribute__((ext_vector_type(8)));
+typedef float bfm_v16f __attribute__((ext_vector_type(16)));
 #define BFM_QB 4      // blocks of 32 queries per wavefront: 512 queries per workgroup
 #define BFM_TR 64     // database rows per tile
-#define BFM_ROWP 272  // bytes per expanded row in LDS (256 + 16: consecutive rows start 16 bytes apart in the banks)
+#define BFM_ROWP 144  // bytes per expanded row in LDS (128 + 16: consecutive rows start 16 bytes apart in the banks)
 #define BFM_LDS (2 * BFM_TR * BFM_ROWP)
 #define BFM_QUERIES_PER_WG (4 * BFM_QB * 32)
-#define BFM_NONE (-100000)  // below any product
+#define BFM_NONE (-100000.f)  // below any product
+#define BFM_SCALE_ONE 0x7f7f7f7f  // E8M0 block scales 2^0
 
-// 16 descriptor bits -> 16 bytes
+// 32 descriptor bits -> 32 FP4 values (16 bytes)
 template <bool QUERY>
-static __device__ __forceinline__ bfm_v4i bfm_expand16(uint32_t bits) {
+static __device__ __forceinline__ bfm_v4i bfm_expand32(uint32_t bits) {
     bfm_v4i o;
 #pragma unroll
     for (int n = 0; n < 4; n++) {
-        const uint32_t nib = (bits >> (4 * n)) & 15u;
-        uint32_t m = __umul24(nib, 0x00204081u) & 0x01010101u;  // bit i of the nibble -> bit 0 of byte i
-        if (QUERY) {
-            m ^= 0x01010101u;                  // 1 where the bit is clear
-            m = ((m << 8) - m) | 0x01010101u;  // 0xFF there, 0x01 where it is set
-        }
+        // the byte's bit i -> bit 1 of nibble i (the FP4 value 1): halves, pairs, single bits apart
+        uint32_t m = ((bits >> (8 * n)) & 255u) << 1;
+        m = (m | (m << 12)) & 0x001E001Eu;
+        m = (m | (m << 6)) & 0x06060606u;
+        m = (m | (m << 3)) & 0x22222222u;
+        if (QUERY) m = 0x22222222u | ((m ^ 0x22222222u) << 2);  // clear bit: the sign on top of the 1
         o[n] = (int)m;
     }
     return o;
@@ -119,20 +123,21 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__
     const int rows = (int)(rEnd - r0);
     if (rows <= 0) return;  // (the whole workgroup; the launcher makes no such chunk)
 
-    bfm_v4i bq[BFM_QB][8];
+    bfm_v4i bq[BFM_QB][4];
     int pcq[BFM_QB];  // popcount of the lane's queries: distance = popcount - product
 #pragma unroll
     for (int b = 0; b < BFM_QB; b++) {
         const long long qi = q0 + b * 32 + c;
         pcq[b] = 0;
 #pragma unroll
-        for (int ks = 0; ks < 8; ks++) {
-            const uint32_t word = qi < nq ? q[qi * 8 + ks] : 0u;
-            pcq[b] += __popc(word);
-            bq[b][ks] = bfm_expand16<true>(h ? word >> 16 : word & 0xffffu);
+        for (int ks = 0; ks < 4; ks++) {
+            const uint32_t w0 = qi < nq ? q[qi * 8 + 2 * ks] : 0u, w1 = qi < nq ? q[qi * 8 + 2 * ks + 1] : 0u;
+            pcq[b] += __popc(w0) + __popc(w1);
+            bq[b][ks] = bfm_expand32<true>(h ? w1 : w0);
         }
     }
-    int best[BFM_QB], sec[BFM_QB], bidx[BFM_QB];
+    float best[BFM_QB], sec[BFM_QB];
+    int bidx[BFM_QB];
 #pragma unroll
     for (int b = 0; b < BFM_QB; b++) best[b] = sec[b] = BFM_NONE, bidx[b] = 0;
 
@@ -144,11 +149,9 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__
         return r < rEnd ? *(const uint2*)(db + r * 8 + 2 * swp) : uint2{0u, 0u};  // (rows past the end: no bit set,
     };                                                                              // and rejected by number below)
     auto stash = [&](int buf, uint2 wds) {
-        uint8_t* d = s_rows + buf * (BFM_TR * BFM_ROWP) + srow * BFM_ROWP + swp * 64;
-        *(bfm_v4i*)(d + 0) = bfm_expand16<false>(wds.x & 0xffffu);
-        *(bfm_v4i*)(d + 16) = bfm_expand16<false>(wds.x >> 16);
-        *(bfm_v4i*)(d + 32) = bfm_expand16<false>(wds.y & 0xffffu);
-        *(bfm_v4i*)(d + 48) = bfm_expand16<false>(wds.y >> 16);
+        uint8_t* d = s_rows + buf * (BFM_TR * BFM_ROWP) + srow * BFM_ROWP + swp * 32;
+        *(bfm_v4i*)(d + 0) = bfm_expand32<false>(wds.x);
+        *(bfm_v4i*)(d + 16) = bfm_expand32<false>(wds.y);
     };
     const int ntiles = (rows + BFM_TR - 1) / BFM_TR;
     stash(0, fetch(0));
@@ -161,32 +164,34 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__
         const uint8_t* base = s_rows + buf * (BFM_TR * BFM_ROWP) + c * BFM_ROWP + h * 16;
 #pragma unroll
         for (int rb = 0; rb < BFM_TR / 32; rb++) {
-            bfm_v16i acc[BFM_QB];
+            bfm_v16f acc[BFM_QB];
 #pragma unroll
-            for (int ks = 0; ks < 8; ks++) {
-                const bfm_v4i a = *(const bfm_v4i*)(base + rb * 32 * BFM_ROWP + ks * 32);
+            for (int ks = 0; ks < 4; ks++) {
+                const bfm_v4i a4 = *(const bfm_v4i*)(base + rb * 32 * BFM_ROWP + ks * 32);
+                const bfm_v8i a = {a4[0], a4[1], a4[2], a4[3], 0, 0, 0, 0};  // (FP4 operands are the low four registers)
 #pragma unroll
                 for (int b = 0; b < BFM_QB; b++) {
+                    const bfm_v8i bb = {bq[b][ks][0], bq[b][ks][1], bq[b][ks][2], bq[b][ks][3], 0, 0, 0, 0};
                     if (ks == 0) {
-                        const bfm_v16i zero = {};
-                        acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[b][ks], zero, 0, 0, 0);
+                        const bfm_v16f zero = {};
+                        acc[b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, zero, 4, 4, 0, BFM_SCALE_ONE, 0, BFM_SCALE_ONE);
                     } else {
-                        acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[b][ks], acc[b], 0, 0, 0);
+                        acc[b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, acc[b], 4, 4, 0, BFM_SCALE_ONE, 0, BFM_SCALE_ONE);
                     }
                 }
             }
             const int rowBase = tile * BFM_TR + rb * 32 + 4 * h;
 #pragma unroll
             for (int b = 0; b < BFM_QB; b++) {
-                const bfm_v16i s = acc[b];
-                int m = max(max(max(s[0], s[1]), max(s[2], s[3])), max(max(s[4], s[5]), max(s[6], s[7])));
-                m = max(m, max(max(max(s[8], s[9]), max(s[10], s[11])), max(max(s[12], s[13]), max(s[14], s[15]))));
+                const bfm_v16f s = acc[b];
+                float m = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+                m = fmaxf(m, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
                 if (__ballot(m > sec[b]) != 0ull) {
                     // rows in ascending order: on equal products the earlier row stays the best, as in a scan
 #pragma unroll
                     for (int i = 0; i < 16; i++) {
                         const int r = rowBase + (i & 3) + 8 * (i >> 2);
-                        const int v = s[i];
+                        const float v = s[i];
                         if (r < rows && v > sec[b]) {
                             if (v > best[b]) {
                                 sec[b] = best[b];
@@ -207,8 +212,8 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__
     for (int b = 0; b < BFM_QB; b++) {
         const long long qi = q0 + b * 32 + c;
         if (qi < nq) {
-            const unsigned long long bd = best[b] == BFM_NONE ? (unsigned long long)BF_NONE : (unsigned long long)(pcq[b] - best[b]);
-            const unsigned long long sd = sec[b] == BFM_NONE ? (unsigned long long)BF_NONE : (unsigned long long)(pcq[b] - sec[b]);
+            const unsigned long long bd = best[b] == BFM_NONE ? (unsigned long long)BF_NONE : (unsigned long long)(pcq[b] - (int)best[b]);
+            const unsigned long long sd = sec[b] == BFM_NONE ? (unsigned long long)BF_NONE : (unsigned long long)(pcq[b] - (int)sec[b]);
             const unsigned long long idx =
                 best[b] == BFM_NONE ? 0xFFFFFFFFull : (unsigned long long)(globalBase + r0 + bidx[b]) & 0xFFFFFFFFull;
             partial[((long long)blockIdx.y * 2 + h) * nq + qi] = (bd << 48) | (sd << 32) | idx;

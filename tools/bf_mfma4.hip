@@ -1,0 +1,289 @@
+// Development prototype (FP4 form): brute-force Hamming top-2 on the matrix cores.  Descriptor bits become bytes +1 / -1, so
+// that the dot product of two descriptors is 256 - 2 * (Hamming distance); v_mfma_i32_32x32x32_i8 then makes 32 rows
+// x 32 queries x 32 bits per instruction.  Stand-alone: generates data, runs the kernel, checks a sample of queries
+// against a CPU scan, prints Gcmp/s.  Build: hipcc --offload-arch=gfx950 -O3 tools/bf_mfma.hip -o tools/bf_mfma
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x)                                                                        \
+    do {                                                                                \
+        hipError_t e_ = (x);                                                            \
+        if (e_ != hipSuccess) {                                                         \
+            fprintf(stderr, "%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); \
+            return 1;                                                                   \
+        }                                                                               \
+    } while (0)
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+#ifndef QB
+#define QB 4  // blocks of 32 queries per wavefront
+#endif
+#ifndef TR
+#define TR 64  // database rows per tile
+#endif
+#define ROWP 144  // bytes per expanded row in LDS (256 + 16: rows 16 apart meet on the same banks, not rows 1 apart)
+#define SENT (-100000.f)
+
+// 32 descriptor bits -> 32 FP4 (E2M1) values, 16 bytes.  Database rows: 1.0 (0x2) for a set bit, 0.0 for a clear one.
+// Queries: +1.0 (0x2) for a set bit, -1.0 (0xA) for a clear one.
+template <bool QUERY>
+static __device__ __forceinline__ v4i expand32(uint32_t bits) {
+    v4i o;
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        // the byte's bit i -> bit 1 of nibble i: halves, pairs, single bits apart, each step one shift-or and one mask
+        uint32_t m = ((bits >> (8 * n)) & 255u) << 1;
+        m = (m | (m << 12)) & 0x001E001Eu;
+        m = (m | (m << 6)) & 0x06060606u;
+        m = (m | (m << 3)) & 0x22222222u;
+        if (QUERY) m = 0x22222222u | ((m ^ 0x22222222u) << 2);  // clear bit: sign bit (0x8) on top of 1.0
+        o[n] = (int)m;
+    }
+    return o;
+}
+
+__global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__ q, int nq, const uint32_t* __restrict__ db,
+                                                 long long n, long long rowsPerChunk, long long globalBase,
+                                                 unsigned long long* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_rows[];  // two buffers of TR expanded rows
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, h = lane >> 5, c = lane & 31;
+    const long long q0 = (long long)blockIdx.x * (4 * QB * 32) + w * (QB * 32);
+    const long long r0 = (long long)blockIdx.y * rowsPerChunk;
+    const long long rEnd = std::min(n, r0 + rowsPerChunk);
+    const int rows = (int)(rEnd - r0);
+    if (rows <= 0) return;  // (whole workgroup)
+
+    // the wavefront's queries as B operands: lane (c, h) holds bits [32 ks + 16 h, + 16) of query c of each block
+    v4i bq[QB][4];
+#pragma unroll
+    for (int b = 0; b < QB; b++) {
+        const long long qi = q0 + b * 32 + c;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const uint32_t word = qi < nq ? q[qi * 8 + 2 * ks + h] : 0u;
+            bq[b][ks] = expand32<true>(word);
+        }
+    }
+    int pcq[QB];
+#pragma unroll
+    for (int b = 0; b < QB; b++) {
+        const long long qi = q0 + b * 32 + c;
+        pcq[b] = 0;
+        if (qi < nq)
+            for (int ks = 0; ks < 8; ks++) pcq[b] += __popc(q[qi * 8 + ks]);
+    }
+    float best[QB], sec[QB];
+    int bidx[QB];
+#pragma unroll
+    for (int b = 0; b < QB; b++) best[b] = sec[b] = SENT, bidx[b] = 0;
+
+    // staging: thread = (row t / 4, word pair t % 4), TR / 64 rows per thread and tile
+    const int srow = t >> 2, swp = t & 3;
+    constexpr int SP = TR / 64;
+    struct Words { uint2 w[SP]; };
+    auto fetch = [&](int tile) -> Words {
+        Words o;
+#pragma unroll
+        for (int p = 0; p < SP; p++) {
+            const long long r = r0 + (long long)tile * TR + srow + 64 * p;
+            o.w[p] = r < rEnd ? *(const uint2*)(db + r * 8 + 2 * swp) : uint2{0u, 0u};
+        }
+        return o;
+    };
+    auto stash = [&](int buf, int tile, const Words& wds) {
+#pragma unroll
+        for (int p = 0; p < SP; p++) {
+            uint8_t* d = s_rows + buf * (TR * ROWP) + (srow + 64 * p) * ROWP + swp * 32;
+            const bool valid = r0 + (long long)tile * TR + srow + 64 * p < rEnd;
+#ifdef USE_LUT
+            const uint32_t* lut = (const uint32_t*)(s_rows + 2 * TR * ROWP);
+            const uint32_t wx = valid ? wds.w[p].x : 0u, wy = valid ? wds.w[p].y : 0u;
+            *(v4i*)(d + 0) = v4i{(int)lut[wx & 255u], (int)lut[(wx >> 8) & 255u], (int)lut[(wx >> 16) & 255u], (int)lut[wx >> 24]};
+            *(v4i*)(d + 16) = v4i{(int)lut[wy & 255u], (int)lut[(wy >> 8) & 255u], (int)lut[(wy >> 16) & 255u], (int)lut[wy >> 24]};
+#else
+            *(v4i*)(d + 0) = expand32<false>(valid ? wds.w[p].x : 0u);
+            *(v4i*)(d + 16) = expand32<false>(valid ? wds.w[p].y : 0u);
+#endif
+        }
+    };
+#ifdef USE_LUT
+    // byte value -> its eight bits as FP4 nibbles
+    uint32_t* lutw = (uint32_t*)(s_rows + 2 * TR * ROWP);
+    {
+        uint32_t m = (uint32_t)t << 1;
+        m = (m | (m << 12)) & 0x001E001Eu;
+        m = (m | (m << 6)) & 0x06060606u;
+        m = (m | (m << 3)) & 0x22222222u;
+        lutw[t] = m;
+    }
+    __syncthreads();
+#endif
+    const int ntiles = (rows + TR - 1) / TR;
+    stash(0, 0, fetch(0));
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; tile++) {
+        const int buf = tile & 1;
+        const bool more = tile + 1 < ntiles;
+        Words nextw = {};
+        if (more) nextw = fetch(tile + 1);
+        const uint8_t* base = s_rows + buf * (TR * ROWP) + c * ROWP + h * 16;
+#pragma unroll
+        for (int rb = 0; rb < TR / 32; rb++) {
+            v16f acc[QB];
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const v4i a4 = *(const v4i*)(base + rb * 32 * ROWP + ks * 32);
+                const v8i a = {a4[0], a4[1], a4[2], a4[3], 0, 0, 0, 0};
+#pragma unroll
+                for (int b = 0; b < QB; b++) {
+                    const v8i bb = {bq[b][ks][0], bq[b][ks][1], bq[b][ks][2], bq[b][ks][3], 0, 0, 0, 0};
+                    if (ks == 0) {
+                        const v16f zero = {};
+                        acc[b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, zero, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                    } else {
+                        acc[b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, acc[b], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                    }
+                }
+            }
+            const int rowBase = tile * TR + rb * 32 + 4 * h;
+#pragma unroll
+            for (int b = 0; b < QB; b++) {
+                const v16f s = acc[b];
+                float m = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+                m = fmaxf(m, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
+#ifdef NO_EPI
+                if (m == 12345) best[b] = m;
+                if (false) {
+#else
+                if (__ballot(m > sec[b]) != 0ull) {
+#endif
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int r = rowBase + (i & 3) + 8 * (i >> 2);
+                        const float v = s[i];
+                        if (r < rows && v > sec[b]) {
+                            if (v > best[b]) {
+                                sec[b] = best[b];
+                                best[b] = v;
+                                bidx[b] = r;
+                            } else {
+                                sec[b] = v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#ifndef NO_EXPAND
+        if (more) stash(buf ^ 1, tile + 1, nextw);
+#else
+        if (more && tile == 0) stash(buf ^ 1, tile + 1, nextw);
+#endif
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < QB; b++) {
+        const long long qi = q0 + b * 32 + c;
+        if (qi < nq) {
+            const unsigned long long bd = best[b] == SENT ? 0xFFFFull : (unsigned long long)(pcq[b] - (int)best[b]);
+            const unsigned long long sd = sec[b] == SENT ? 0xFFFFull : (unsigned long long)(pcq[b] - (int)sec[b]);
+            const unsigned long long idx =
+                best[b] == SENT ? 0xFFFFFFFFull : (unsigned long long)(globalBase + r0 + bidx[b]) & 0xFFFFFFFFull;
+            partial[((long long)blockIdx.y * 2 + h) * nq + qi] = (bd << 48) | (sd << 32) | idx;
+        }
+    }
+}
+
+static uint64_t rng_state = 88172645463325252ull;
+static uint64_t rnd() {
+    rng_state ^= rng_state << 13;
+    rng_state ^= rng_state >> 7;
+    rng_state ^= rng_state << 17;
+    return rng_state;
+}
+
+int main(int argc, char** argv) {
+    const long long n = argc > 1 ? atoll(argv[1]) : 1000000;
+    const int nq = argc > 2 ? atoi(argv[2]) : 20000;
+    const int reps = argc > 3 ? atoi(argv[3]) : 3;
+    std::vector<uint32_t> db((size_t)n * 8), q((size_t)nq * 8);
+    for (auto& x : db) x = (uint32_t)rnd();
+    for (int i = 0; i < nq; i++) {
+        const long long src = (long long)(rnd() % (uint64_t)n);
+        for (int k = 0; k < 8; k++) q[(size_t)i * 8 + k] = (i % 3 == 0) ? db[(size_t)src * 8 + k] : (uint32_t)rnd();
+        if (i % 3 == 0) {  // a near duplicate of a database row: a few flipped bits
+            const int flips = (int)(rnd() % 40);
+            for (int f = 0; f < flips; f++) q[(size_t)i * 8 + (rnd() & 7)] ^= 1u << (rnd() & 31);
+        }
+    }
+    for (int k = 0; k < 8; k++) {  // exact duplicates in the database: ties on the best row
+        db[(size_t)(n - 5) * 8 + k] = db[(size_t)7 * 8 + k];
+        q[k] = db[(size_t)7 * 8 + k];
+    }
+    uint32_t *dDb, *dQ;
+    unsigned long long* dPart;
+    CHECK(hipMalloc((void**)&dDb, db.size() * 4));
+    CHECK(hipMalloc((void**)&dQ, q.size() * 4));
+    CHECK(hipMemcpy(dDb, db.data(), db.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(dQ, q.data(), q.size() * 4, hipMemcpyHostToDevice));
+    const int qGroups = (nq + 4 * QB * 32 - 1) / (4 * QB * 32);
+    int chunks = std::max(1, (int)(2 * 512 / qGroups));
+    long long rpc = (n + chunks - 1) / chunks;
+    rpc = (rpc + TR - 1) / TR * TR;
+    chunks = (int)((n + rpc - 1) / rpc);
+    CHECK(hipMalloc((void**)&dPart, (size_t)2 * chunks * nq * 8));
+    const size_t lds = 2 * TR * ROWP + 2048;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int r = 0; r < reps + 1; r++) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_bf_mfma, dim3(qGroups, chunks), dim3(256), lds, 0, dQ, nq, dDb, n, rpc, 0ll, dPart);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0) best = std::min(best, ms);
+    }
+    CHECK(hipGetLastError());
+    printf("QB %d TR %d: %lld rows x %d queries, %d x %d workgroups: %.3f ms = %.0f Gcmp/s\n", QB, TR, n, nq, qGroups, chunks, best,
+           (double)n * nq / (best * 1e-3) / 1e9);
+    std::vector<unsigned long long> part((size_t)2 * chunks * nq);
+    CHECK(hipMemcpy(part.data(), dPart, part.size() * 8, hipMemcpyDeviceToHost));
+    int bad = 0;
+    const int step = std::max(1, nq / 96);
+    for (int i = 0; i < nq; i += step) {
+        // device: merge the partial words as the library's merge kernel does
+        uint32_t bd = 0xFFFF, sd = 0xFFFF, bi = 0xFFFFFFFFu;
+        for (int s = 0; s < 2 * chunks; s++) {
+            const unsigned long long p = part[(size_t)s * nq + i];
+            const uint32_t d = (uint32_t)(p >> 48), d2 = (uint32_t)(p >> 32) & 0xFFFFu, idx = (uint32_t)p;
+            if (d == 0xFFFF) continue;
+            if (d < bd || (d == bd && idx < bi)) { sd = bd; bd = d; bi = idx; } else if (d < sd) sd = d;
+            if (d2 < sd) sd = d2;
+        }
+        // host scan
+        uint32_t rb = 0xFFFF, rs = 0xFFFF, ri = 0xFFFFFFFFu;
+        for (long long r = 0; r < n; r++) {
+            uint32_t d = 0;
+            for (int k = 0; k < 8; k++) d += (uint32_t)__builtin_popcount(db[(size_t)r * 8 + k] ^ q[(size_t)i * 8 + k]);
+            if (d < rb) { rs = rb; rb = d; ri = (uint32_t)r; } else if (d < rs) rs = d;
+        }
+        if (bd != rb || sd != rs || bi != ri) {
+            if (bad < 5) printf("query %d: device (%u, %u, %u) host (%u, %u, %u)\n", i, bd, sd, bi, rb, rs, ri);
+            bad++;
+        }
+    }
+    printf("%d of %d checked queries differ\n", bad, (nq + step - 1) / step);
+    return bad ? 1 : 0;
+}
