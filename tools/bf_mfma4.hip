@@ -1,4 +1,8 @@
-// Development prototype (FP4 form): brute-force Hamming top-2 on the matrix cores.  Descriptor bits become bytes +1 / -1, so
+// Development prototype (FP4 form): brute-force Hamming top-2 on the matrix cores.  Build-time switches for
+// measurements: -DNO_LDS / -DNO_EXPAND / -DNO_EPI drop the operand reads, the row expansion, the top-2 filter (shares
+// of the run time); -DPREX scans a database expanded once in global memory; -DPD=n lets the global loads run n tiles
+// ahead; -DWIDE accumulates all row blocks of a tile before any is looked at; -DUSE_LUT expands through a table in LDS.
+// None of PREX, PD, WIDE, USE_LUT changed the rate by more than 2 %.  Descriptor bits become bytes +1 / -1, so
 // that the dot product of two descriptors is 256 - 2 * (Hamming distance); v_mfma_i32_32x32x32_i8 then makes 32 rows
 // x 32 queries x 32 bits per instruction.  Stand-alone: generates data, runs the kernel, checks a sample of queries
 // against a CPU scan, prints Gcmp/s.  Build: hipcc --offload-arch=gfx950 -O3 tools/bf_mfma.hip -o tools/bf_mfma
@@ -51,6 +55,11 @@ static __device__ __forceinline__ v4i expand32(uint32_t bits) {
     return o;
 }
 
+__global__ void k_expand(const uint32_t* __restrict__ db, long long n, v4i* __restrict__ dbx) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // one word of the database per thread
+    if (i < n * 8) dbx[i] = expand32<false>(db[i]);
+}
+
 __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__ q, int nq, const uint32_t* __restrict__ db,
                                                  long long n, long long rowsPerChunk, long long globalBase,
                                                  unsigned long long* __restrict__ partial) {
@@ -89,13 +98,24 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__
     // staging: thread = (row t / 4, word pair t % 4), TR / 64 rows per thread and tile
     const int srow = t >> 2, swp = t & 3;
     constexpr int SP = TR / 64;
+#ifdef PREX
+    struct Words { v4i w[SP][2]; };
+#else
     struct Words { uint2 w[SP]; };
+#endif
     auto fetch = [&](int tile) -> Words {
         Words o;
 #pragma unroll
         for (int p = 0; p < SP; p++) {
             const long long r = r0 + (long long)tile * TR + srow + 64 * p;
+#ifdef PREX
+            const v4i z = {0, 0, 0, 0};
+            const v4i* src = (const v4i*)db + r * 8 + 2 * swp;  // (db is the expanded database here: 8 x 16 bytes per row)
+            o.w[p][0] = r < rEnd ? src[0] : z;
+            o.w[p][1] = r < rEnd ? src[1] : z;
+#else
             o.w[p] = r < rEnd ? *(const uint2*)(db + r * 8 + 2 * swp) : uint2{0u, 0u};
+#endif
         }
         return o;
     };
@@ -104,7 +124,10 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__
         for (int p = 0; p < SP; p++) {
             uint8_t* d = s_rows + buf * (TR * ROWP) + (srow + 64 * p) * ROWP + swp * 32;
             const bool valid = r0 + (long long)tile * TR + srow + 64 * p < rEnd;
-#ifdef USE_LUT
+#ifdef PREX
+            *(v4i*)(d + 0) = wds.w[p][0];
+            *(v4i*)(d + 16) = wds.w[p][1];
+#elif defined(USE_LUT)
             const uint32_t* lut = (const uint32_t*)(s_rows + 2 * TR * ROWP);
             const uint32_t wx = valid ? wds.w[p].x : 0u, wy = valid ? wds.w[p].y : 0u;
             *(v4i*)(d + 0) = v4i{(int)lut[wx & 255u], (int)lut[(wx >> 8) & 255u], (int)lut[(wx >> 16) & 255u], (int)lut[wx >> 24]};
@@ -128,16 +151,49 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__
     __syncthreads();
 #endif
     const int ntiles = (rows + TR - 1) / TR;
+#ifndef PD
+#define PD 1  // tiles the global loads run ahead of the tile being computed
+#endif
     stash(0, 0, fetch(0));
+    Words ring[PD];
+#pragma unroll
+    for (int k = 0; k < PD; k++) ring[k] = fetch(1 + k);  // (past the end: zero words, never stashed)
     __syncthreads();
     for (int tile = 0; tile < ntiles; tile++) {
         const int buf = tile & 1;
         const bool more = tile + 1 < ntiles;
-        Words nextw = {};
-        if (more) nextw = fetch(tile + 1);
+        const Words nextw = ring[0];  // tile + 1, requested PD tiles ago
+#pragma unroll
+        for (int k = 0; k + 1 < PD; k++) ring[k] = ring[k + 1];
+        ring[PD - 1] = fetch(tile + 1 + PD);
         const uint8_t* base = s_rows + buf * (TR * ROWP) + c * ROWP + h * 16;
+#ifdef WIDE
+        constexpr int NRB = TR / 32;
+        v16f accw[NRB][QB];
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; rb++) {
+                const v4i a4 = *(const v4i*)(base + rb * 32 * ROWP + ks * 32);
+                const v8i a = {a4[0], a4[1], a4[2], a4[3], 0, 0, 0, 0};
+#pragma unroll
+                for (int b = 0; b < QB; b++) {
+                    const v8i bb = {bq[b][ks][0], bq[b][ks][1], bq[b][ks][2], bq[b][ks][3], 0, 0, 0, 0};
+                    if (ks == 0) {
+                        const v16f zero = {};
+                        accw[rb][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, zero, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                    } else {
+                        accw[rb][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, accw[rb][b], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                    }
+                }
+            }
+        }
+#endif
 #pragma unroll
         for (int rb = 0; rb < TR / 32; rb++) {
+#ifdef WIDE
+            v16f (&acc)[QB] = accw[rb];
+#else
             v16f acc[QB];
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
@@ -154,6 +210,7 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__
                     }
                 }
             }
+#endif
             const int rowBase = tile * TR + rb * 32 + 4 * h;
 #pragma unroll
             for (int b = 0; b < QB; b++) {
@@ -235,8 +292,17 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc((void**)&dQ, q.size() * 4));
     CHECK(hipMemcpy(dDb, db.data(), db.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(dQ, q.data(), q.size() * 4, hipMemcpyHostToDevice));
+#ifdef PREX
+    v4i* dDbx;
+    CHECK(hipMalloc((void**)&dDbx, (size_t)n * 128));
+    hipLaunchKernelGGL(k_expand, dim3((unsigned)((n * 8 + 255) / 256)), dim3(256), 0, 0, dDb, n, dDbx);
+    CHECK(hipDeviceSynchronize());
+    const uint32_t* dScan = (const uint32_t*)dDbx;
+#else
+    const uint32_t* dScan = dDb;
+#endif
     const int qGroups = (nq + 4 * QB * 32 - 1) / (4 * QB * 32);
-    int chunks = std::max(1, (int)(2 * 512 / qGroups));
+    int chunks = std::max(1, (int)((argc > 4 ? atoi(argv[4]) : 2 * 512) / qGroups));
     long long rpc = (n + chunks - 1) / chunks;
     rpc = (rpc + TR - 1) / TR * TR;
     chunks = (int)((n + rpc - 1) / rpc);
@@ -248,7 +314,7 @@ int main(int argc, char** argv) {
     float best = 1e30f;
     for (int r = 0; r < reps + 1; r++) {
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k_bf_mfma, dim3(qGroups, chunks), dim3(256), lds, 0, dQ, nq, dDb, n, rpc, 0ll, dPart);
+        hipLaunchKernelGGL(k_bf_mfma, dim3(qGroups, chunks), dim3(256), lds, 0, dQ, nq, dScan, n, rpc, 0ll, dPart);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms;
