@@ -462,6 +462,37 @@ def test_brute_force_top2(hip, oracle):
     bf.close()
 
 
+def test_brute_force_random_shapes(hip, oracle):
+    """Row and query counts around the scan's block sizes (32 rows and 32 queries per matrix instruction, 64 rows per
+    tile, 512 queries per workgroup), descriptors of extreme weight (the distance is formed as popcount(query) minus a
+    dot product), many ties, a row numbering that does not start at 0."""
+    rng = np.random.default_rng(77)
+    bf = hip.BruteForce(0)
+    for nd, nq in ((31, 33), (32, 32), (33, 31), (63, 511), (64, 512), (65, 513), (127, 1), (4099, 1025), (70001, 97)):
+        db = rng.integers(0, 256, (nd, 32), dtype=np.uint8)
+        q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+        db[rng.integers(0, nd)] = 0      # no bit set
+        db[rng.integers(0, nd)] = 255    # every bit set
+        q[rng.integers(0, nq)] = 0
+        q[rng.integers(0, nq)] = 255
+        for k in range(min(nq, 40)):     # exact copies of rows, some of them twice in the database
+            r = int(rng.integers(0, nd))
+            q[k] = db[r]
+            if k % 3 == 0:
+                db[int(rng.integers(0, nd))] = db[r]
+        sparse = rng.integers(0, nd, max(1, nd // 7))
+        db[sparse] &= rng.integers(0, 256, (len(sparse), 32), dtype=np.uint8) & 0x11  # light rows
+        base = int(rng.integers(0, 1 << 20))
+        bf.set_database(db, base)
+        ig, bg, sg = bf.query_top2(q)
+        io, bo, so = oracle.bf_top2(q, db)
+        io = np.where(io >= 0, io + base, io)
+        np.testing.assert_array_equal(ig, io, err_msg="%d rows, %d queries" % (nd, nq))
+        np.testing.assert_array_equal(bg, bo)
+        np.testing.assert_array_equal(sg, so)
+    bf.close()
+
+
 def test_brute_force_sharded_merge(hip, oracle):
     """Row shards on one device, packed per-shard results merged by the merge
     kernel: equals the scan of the whole database (the all-gather only moves
