@@ -184,8 +184,13 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__
 #pragma unroll
             for (int b = 0; b < BFM_QB; b++) {
                 const bfm_v16f s = acc[b];
-                float m = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
-                m = fmaxf(m, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
+                // eight three-input maxima (v_max3_f32) for the sixteen products; the file is built with
+                // -fno-honor-nans (Makefile), or each would first be canonicalised by a v_max_f32 x, x of its own
+#define BFM_MAX3(a, b, c) fmaxf(fmaxf(a, b), c)
+                const float m0 = BFM_MAX3(s[0], s[1], s[2]), m1 = BFM_MAX3(s[3], s[4], s[5]), m2 = BFM_MAX3(s[6], s[7], s[8]);
+                const float m3 = BFM_MAX3(s[9], s[10], s[11]), m4 = BFM_MAX3(s[12], s[13], s[14]);
+                const float m = BFM_MAX3(BFM_MAX3(m0, m1, m2), BFM_MAX3(m3, m4, s[15]), m0);
+#undef BFM_MAX3
                 if (__ballot(m > sec[b]) != 0ull) {
                     // rows in ascending order: on equal products the earlier row stays the best, as in a scan
 #pragma unroll

@@ -215,8 +215,13 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__
 #pragma unroll
             for (int b = 0; b < QB; b++) {
                 const v16f s = acc[b];
-                float m = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
-                m = fmaxf(m, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
+                // (three-input maxima: eight instructions for the sixteen values when the file is built with
+                // -fno-honor-nans; otherwise every accumulator first goes through a canonicalising v_max_f32 x, x)
+#define MAX3(a, b, c) fmaxf(fmaxf(a, b), c)
+                const float m0 = MAX3(s[0], s[1], s[2]), m1 = MAX3(s[3], s[4], s[5]), m2 = MAX3(s[6], s[7], s[8]);
+                const float m3 = MAX3(s[9], s[10], s[11]), m4 = MAX3(s[12], s[13], s[14]);
+                const float m = MAX3(MAX3(m0, m1, m2), MAX3(m3, m4, s[15]), m0);
+#undef MAX3
 #ifdef NO_EPI
                 if (m == 12345) best[b] = m;
                 if (false) {
