@@ -279,7 +279,7 @@ def main():
                          "peak": round(MFMA_FP4_OPS / 1e12, 1), "unit": "TOP/s",
                          "frac": round(kern_gcmp * 1e9 * 512 / MFMA_FP4_OPS, 4),
                          "peak_source": "dense FP4 MFMA: 4096 operations per cycle and SIMD x 1024 SIMDs x 2.4 GHz; a comparison is 256 multiply-adds",
-                         "int8_form_gcmp_per_s": 6204,
+                         "int8_form_gcmp_per_s": 6204,  # measured when the scan used v_mfma_i32_32x32x32_i8
                          "vector_alu_form": {"what": "the same scan as 8 x (v_xor_b32 + v_bcnt_u32_b32) per comparison, the library's kernel until this one (tools/bf_valu_scan.inc)",
                                              "gcmp_per_s": 2734, "ceiling_gcmp_per_s": round(VALU_LANE_OPS / 16 / 1e9),
                                              "this_kernel_over_its_ceiling": round(lane_ops / VALU_LANE_OPS, 3)},

@@ -77,8 +77,7 @@ static int bf_static_block(int device, unsigned long long** out) {
 // A wavefront keeps BFM_QB blocks of 32 queries as B operands in registers for the whole scan (lane (c, h) holds word
 // 2 ks + h of query c for the four k-steps ks; the A operand below uses the same bit order, which is all the
 // products need).  The workgroup's four wavefronts share the database rows: 256 threads fetch a tile of BFM_TR rows
-// as bits (8 bytes per thread), expand them to FP4 in LDS (three shift-or / mask steps spread a byte's bits over
-// eight nibbles), two tiles in flight, and every wavefront reads its A operands from there with ds_read_b128.  The
+// as bits (8 bytes per thread), expand them to FP4 in LDS (five instructions per byte, see bfm_expand32), two tiles in flight, and every wavefront reads its A operands from there with ds_read_b128.  The
 // 32 x 32 products of a (row block, query block) arrive with the query on the lane and 16 rows in 16 registers
 // (row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)): a lane keeps the top-2 of one query over its rows — the maximum
 // of the 16 against the query's second best decides whether the registers are looked at one by one, which is rare
@@ -101,11 +100,13 @@ static __device__ __forceinline__ bfm_v4i bfm_expand32(uint32_t bits) {
     bfm_v4i o;
 #pragma unroll
     for (int n = 0; n < 4; n++) {
-        // the byte's bit i -> bit 1 of nibble i (the FP4 value 1): halves, pairs, single bits apart
-        uint32_t m = ((bits >> (8 * n)) & 255u) << 1;
-        m = (m | (m << 12)) & 0x001E001Eu;
-        m = (m | (m << 6)) & 0x06060606u;
-        m = (m | (m << 3)) & 0x22222222u;
+        // the byte's bit i -> bit 1 of nibble i (the FP4 value 1), five instructions: the byte's four bit pairs are
+        // brought to the low bits of four bytes (shifted copies ORed together: no kept bit is hit twice), and each
+        // pair selects a byte of the table {0x00, 0x02, 0x20, 0x22} through v_perm_b32
+        uint32_t m = (bits >> (8 * n)) & 255u;
+        m |= m << 6;
+        m |= m << 12;
+        m = __builtin_amdgcn_perm(0u, 0x22200200u, m & 0x03030303u);
         if (QUERY) m = 0x22222222u | ((m ^ 0x22222222u) << 2);  // clear bit: the sign on top of the 1
         o[n] = (int)m;
     }

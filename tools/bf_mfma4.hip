@@ -44,11 +44,21 @@ static __device__ __forceinline__ v4i expand32(uint32_t bits) {
     v4i o;
 #pragma unroll
     for (int n = 0; n < 4; n++) {
+#ifdef PERM
+        // two bits -> one byte of two nibbles through v_perm_b32: the byte's four bit pairs are brought to the low bits
+        // of four bytes (shifted copies ORed together: no kept bit is hit twice), and each selects a byte of the
+        // table {0x00, 0x02, 0x20, 0x22}
+        uint32_t m = (bits >> (8 * n)) & 255u;
+        m |= m << 6;
+        m |= m << 12;
+        m = __builtin_amdgcn_perm(0u, 0x22200200u, m & 0x03030303u);
+#else
         // the byte's bit i -> bit 1 of nibble i: halves, pairs, single bits apart, each step one shift-or and one mask
         uint32_t m = ((bits >> (8 * n)) & 255u) << 1;
         m = (m | (m << 12)) & 0x001E001Eu;
         m = (m | (m << 6)) & 0x06060606u;
         m = (m | (m << 3)) & 0x22222222u;
+#endif
         if (QUERY) m = 0x22222222u | ((m ^ 0x22222222u) << 2);  // clear bit: sign bit (0x8) on top of 1.0
         o[n] = (int)m;
     }
