@@ -77,12 +77,26 @@ static int bf_static_block(int device, unsigned long long** out) {
 // A wavefront keeps BFM_QB blocks of 32 queries as B operands in registers for the whole scan (lane (c, h) holds word
 // 2 ks + h of query c for the four k-steps ks; the A operand below uses the same bit order, which is all the
 // products need).  The workgroup's four wavefronts share the database rows: 256 threads fetch a tile of BFM_TR rows
-// as bits (8 bytes per thread), expand them to FP4 in LDS (five instructions per byte, see bfm_expand32), two tiles in flight, and every wavefront reads its A operands from there with ds_read_b128.  The
-// 32 x 32 products of a (row block, query block) arrive with the query on the lane and 16 rows in 16 registers
-// (row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)): a lane keeps the top-2 of one query over its rows — the maximum
-// of the 16 against the query's second best decides whether the registers are looked at one by one, which is rare
-// after the first rows of a chunk — and the two lanes of a query report separately: the merge kernel combines them
-// like two chunks.  Chunks along blockIdx.y as before.
+// as bits (8 bytes per thread), expand them to FP4 in LDS (five instructions per byte, see bfm_expand32), two tiles in
+// flight, and every wavefront reads its A operands from there with ds_read_b128.  The 32 x 32 products of a (row
+// block, query block) arrive with the query on the lane and 16 rows in 16 registers (row = (reg & 3) + 8 (reg >> 2) +
+// 4 (lane >> 5)): a lane keeps the top-2 of one query over its rows, and the two lanes of a query report separately
+// (the merge kernel combines them like two chunks).
+//
+// What the vector ALU does beside the matrix instructions decides the rate, in three ways:
+//  * A matrix instruction holds the SIMD's issue port for part of its 32 cycles only; about four independent vector
+//    instructions fit beside it, but a wavefront issues in order, so they have to stand between the matrix
+//    instructions in the instruction stream.  The tile's two row blocks therefore use two sets of accumulators:
+//    while the 16 matrix instructions of one block run, the filter of the other block's finished products (the
+//    maximum of a lane's 16 against the query's threshold: eight v_max3_f32 and a compare per query block) and the
+//    expansion of the next tile's rows are issued between them (bfm_half; sched_group_barrier gives the order).
+//  * Looking at the 16 registers one by one happens only for query blocks in which some lane passed the filter.
+//    That costs a few hundred cycles with no matrix instruction in flight, so how often it happens matters: the
+//    threshold is the larger second best of the query's two lanes, raised by what the other chunks of the same query,
+//    which run side by side, have published in `shared` (bfm_publish / the refresh in the tile loop).
+//  * The file is built with -fno-honor-nans (or every accumulator is canonicalised by a v_max_f32 x, x before a
+//    maximum) and with machine-code sinking disabled (or the matrix instructions, whose results are first used a
+//    branch later, are moved out of the block they were interleaved in).
 typedef int bfm_v4i __attribute__((ext_vector_type(4)));
 typedef int bfm_v8i __attribute__((ext_vector_type(8)));
 typedef float bfm_v16f __attribute__((ext_vector_type(16)));
@@ -113,9 +127,14 @@ static __device__ __forceinline__ bfm_v4i bfm_expand32(uint32_t bits) {
     return o;
 }
 
+#define BFM_REFRESH 32  // tiles between two looks at the thresholds the other chunks have published (a power of two)
+#define BFM_BIAS 1024.f // added to a published product: positive, so that the bit patterns order like the values
+
 __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__ q, int nq, const uint32_t* __restrict__ db,
                                                     long long n, long long rowsPerChunk, long long globalBase,
-                                                    unsigned long long* __restrict__ partial) {
+                                                    unsigned long long* __restrict__ partial,
+                                                    uint32_t* __restrict__ shared) {
+    static_assert(BFM_QB == 4 && BFM_TR == 64, "the interleaving is written for four query blocks and two row blocks");
     extern __shared__ __attribute__((aligned(16))) uint8_t s_rows[];  // two buffers of BFM_TR expanded rows
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, h = lane >> 5, c = lane & 31;
     const long long q0 = (long long)blockIdx.x * BFM_QUERIES_PER_WG + w * (BFM_QB * 32);
@@ -137,83 +156,148 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__
             bq[b][ks] = bfm_expand32<true>(h ? w1 : w0);
         }
     }
-    float best[BFM_QB], sec[BFM_QB];
+    // best / sec: the lane's own two largest products; thr: what a product has to beat to matter at all -- the
+    // larger second best of the query's two lanes (they see rows 0-3, 8-11, .. and 4-7, 12-15, .. of every block; a
+    // product that does not beat it has two earlier rows at least as good in one list or the other), or another
+    // chunk's published second best less one half (a product equal to that one may still be the earlier row)
+    float best[BFM_QB], sec[BFM_QB], thr[BFM_QB];
     int bidx[BFM_QB];
+    bool flagged[BFM_QB];  // query blocks in which the last filter pass saw a lane above its threshold
 #pragma unroll
-    for (int b = 0; b < BFM_QB; b++) best[b] = sec[b] = BFM_NONE, bidx[b] = 0;
+    for (int b = 0; b < BFM_QB; b++) best[b] = sec[b] = thr[b] = BFM_NONE, bidx[b] = 0, flagged[b] = false;
 
     // staging: thread = (row t / 4, word pair t % 4) of a tile
-    static_assert(BFM_TR == 64, "one row quarter per thread");
     const int srow = t >> 2, swp = t & 3;
     auto fetch = [&](int tile) -> uint2 {
         const long long r = r0 + (long long)tile * BFM_TR + srow;
         return r < rEnd ? *(const uint2*)(db + r * 8 + 2 * swp) : uint2{0u, 0u};  // (rows past the end: no bit set,
     };                                                                              // and rejected by number below)
-    auto stash = [&](int buf, uint2 wds) {
-        uint8_t* d = s_rows + buf * (BFM_TR * BFM_ROWP) + srow * BFM_ROWP + swp * 32;
-        *(bfm_v4i*)(d + 0) = bfm_expand32<false>(wds.x);
-        *(bfm_v4i*)(d + 16) = bfm_expand32<false>(wds.y);
-    };
-    const int ntiles = (rows + BFM_TR - 1) / BFM_TR;
-    stash(0, fetch(0));
-    __syncthreads();
-    for (int tile = 0; tile < ntiles; tile++) {
-        const int buf = tile & 1;
-        const bool more = tile + 1 < ntiles;
-        uint2 nextw = {0u, 0u};
-        if (more) nextw = fetch(tile + 1);
-        const uint8_t* base = s_rows + buf * (BFM_TR * BFM_ROWP) + c * BFM_ROWP + h * 16;
+
+    // The registers of the flagged query blocks one by one, rows in ascending order: on equal products the earlier
+    // row stays the best, as in a scan.
+    auto update = [&](const bfm_v16f* acc, int rowBase) {
 #pragma unroll
-        for (int rb = 0; rb < BFM_TR / 32; rb++) {
-            bfm_v16f acc[BFM_QB];
+        for (int b = 0; b < BFM_QB; b++) {
+            if (__ballot(flagged[b]) == 0ull) continue;
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-                const bfm_v4i a4 = *(const bfm_v4i*)(base + rb * 32 * BFM_ROWP + ks * 32);
-                const bfm_v8i a = {a4[0], a4[1], a4[2], a4[3], 0, 0, 0, 0};  // (FP4 operands are the low four registers)
-#pragma unroll
-                for (int b = 0; b < BFM_QB; b++) {
-                    const bfm_v8i bb = {bq[b][ks][0], bq[b][ks][1], bq[b][ks][2], bq[b][ks][3], 0, 0, 0, 0};
-                    if (ks == 0) {
-                        const bfm_v16f zero = {};
-                        acc[b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, zero, 4, 4, 0, BFM_SCALE_ONE, 0, BFM_SCALE_ONE);
+            for (int i = 0; i < 16; i++) {
+                const int r = rowBase + (i & 3) + 8 * (i >> 2);
+                const float v = acc[b][i];
+                if (r < rows && v > sec[b]) {
+                    if (v > best[b]) {
+                        sec[b] = best[b];
+                        best[b] = v;
+                        bidx[b] = r;
                     } else {
-                        acc[b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, acc[b], 4, 4, 0, BFM_SCALE_ONE, 0, BFM_SCALE_ONE);
+                        sec[b] = v;
                     }
                 }
             }
-            const int rowBase = tile * BFM_TR + rb * 32 + 4 * h;
+            const float own = fmaxf(sec[b], __shfl_xor(sec[b], 32));
+            thr[b] = fmaxf(thr[b], own);
+            const long long qi = q0 + b * 32 + c;
+            if (h == 0 && qi < nq && own > -BFM_BIAS) atomicMax(&shared[qi], __float_as_uint(own + BFM_BIAS));
+        }
+    };
+
+    // One row block: its 16 matrix instructions (operands at aBase -> accW), and between them the filter of accR,
+    // the products of the block before, and the expansion of one word of the next tile's rows (stored at dst).
+    // Returns whether any lane of the wavefront has a product above its threshold in accR.
+    auto half = [&](const uint8_t* aBase, bfm_v16f* accW, const bfm_v16f* accR, uint32_t word, uint8_t* dst) -> bool {
+        bfm_v4i aK[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) aK[ks] = *(const bfm_v4i*)(aBase + ks * 32);
+        float mm[5], mA = 0.f;
+        bool hit = false;
+        uint32_t ex = 0u;
+        bfm_v4i o = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int ks = j >> 2, b = j & 3;
+            const bfm_v8i a = {aK[ks][0], aK[ks][1], aK[ks][2], aK[ks][3], 0, 0, 0, 0};  // (FP4 operands are the low four registers)
+            const bfm_v8i bb = {bq[b][ks][0], bq[b][ks][1], bq[b][ks][2], bq[b][ks][3], 0, 0, 0, 0};
+            if (ks == 0) {
+                const bfm_v16f zero = {};
+                accW[b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, zero, 4, 4, 0, BFM_SCALE_ONE, 0, BFM_SCALE_ONE);
+            } else {
+                accW[b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, accW[b], 4, 4, 0, BFM_SCALE_ONE, 0, BFM_SCALE_ONE);
+            }
+            // step j of the filter and the expansion: query block / byte j / 4, quarter j % 4
+            const int eb = j >> 2, p = j & 3;
+            const bfm_v16f s = accR[eb];
+#define BFM_MAX3(a, b, c) fmaxf(fmaxf(a, b), c)
+            if (p == 0) {
+                mm[0] = BFM_MAX3(s[0], s[1], s[2]);
+                mm[1] = BFM_MAX3(s[3], s[4], s[5]);
+                ex = (word >> (8 * eb)) & 255u;
+                ex |= ex << 6;
+            } else if (p == 1) {
+                mm[2] = BFM_MAX3(s[6], s[7], s[8]);
+                mm[3] = BFM_MAX3(s[9], s[10], s[11]);
+                ex |= ex << 12;
+            } else if (p == 2) {
+                mm[4] = BFM_MAX3(s[12], s[13], s[14]);
+                mA = BFM_MAX3(mm[0], mm[1], mm[2]);
+                ex &= 0x03030303u;
+            } else {
+                const float m = fmaxf(mA, BFM_MAX3(mm[3], mm[4], s[15]));
+                flagged[eb] = m > thr[eb];
+                hit |= flagged[eb];
+                o[eb] = (int)__builtin_amdgcn_perm(0u, 0x22200200u, ex);  // (as in bfm_expand32)
+            }
+#undef BFM_MAX3
+        }
+        // the order the scheduler is to build from this block: the four operand reads, then one matrix instruction
+        // and up to four vector instructions in turn
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+        *(bfm_v4i*)dst = o;  // (past the last tile: rows that are never read)
+        return __ballot(hit) != 0ull;
+    };
+
+    const int ntiles = (rows + BFM_TR - 1) / BFM_TR;
+    {
+        const uint2 w0 = fetch(0);
+        uint8_t* d = s_rows + srow * BFM_ROWP + swp * 32;
+        *(bfm_v4i*)(d + 0) = bfm_expand32<false>(w0.x);
+        *(bfm_v4i*)(d + 16) = bfm_expand32<false>(w0.y);
+    }
+    uint2 ahead = fetch(1);
+    __syncthreads();
+    bfm_v16f acc0[BFM_QB], acc1[BFM_QB];
+#pragma unroll
+    for (int b = 0; b < BFM_QB; b++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc1[b][i] = BFM_NONE;  // (what the first filter pass looks at)
+    for (int tile = 0; tile < ntiles; tile++) {
+        if ((tile & (BFM_REFRESH - 1)) == BFM_REFRESH - 1) {
 #pragma unroll
             for (int b = 0; b < BFM_QB; b++) {
-                const bfm_v16f s = acc[b];
-                // eight three-input maxima (v_max3_f32) for the sixteen products; the file is built with
-                // -fno-honor-nans (Makefile), or each would first be canonicalised by a v_max_f32 x, x of its own
-#define BFM_MAX3(a, b, c) fmaxf(fmaxf(a, b), c)
-                const float m0 = BFM_MAX3(s[0], s[1], s[2]), m1 = BFM_MAX3(s[3], s[4], s[5]), m2 = BFM_MAX3(s[6], s[7], s[8]);
-                const float m3 = BFM_MAX3(s[9], s[10], s[11]), m4 = BFM_MAX3(s[12], s[13], s[14]);
-                const float m = BFM_MAX3(BFM_MAX3(m0, m1, m2), BFM_MAX3(m3, m4, s[15]), m0);
-#undef BFM_MAX3
-                if (__ballot(m > sec[b]) != 0ull) {
-                    // rows in ascending order: on equal products the earlier row stays the best, as in a scan
-#pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const int r = rowBase + (i & 3) + 8 * (i >> 2);
-                        const float v = s[i];
-                        if (r < rows && v > sec[b]) {
-                            if (v > best[b]) {
-                                sec[b] = best[b];
-                                best[b] = v;
-                                bidx[b] = r;
-                            } else {
-                                sec[b] = v;
-                            }
-                        }
-                    }
+                const long long qi = q0 + b * 32 + c;
+                if (qi < nq) {
+                    const uint32_t g = __hip_atomic_load(&shared[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (g != 0u) thr[b] = fmaxf(thr[b], __uint_as_float(g) - (BFM_BIAS + 0.5f));
                 }
             }
         }
-        if (more) stash(buf ^ 1, nextw);
+        const int buf = tile & 1;
+        const uint2 nextw = ahead;  // tile + 1, requested a tile ago
+        ahead = fetch(tile + 2);
+        const uint8_t* base = s_rows + buf * (BFM_TR * BFM_ROWP) + c * BFM_ROWP + h * 16;
+        uint8_t* d = s_rows + (buf ^ 1) * (BFM_TR * BFM_ROWP) + srow * BFM_ROWP + swp * 32;
+        __builtin_amdgcn_sched_barrier(0);
+        if (half(base, acc0, acc1, nextw.x, d)) update(acc1, (tile - 1) * BFM_TR + 32 + 4 * h);
+        __builtin_amdgcn_sched_barrier(0);
+        if (half(base + 32 * BFM_ROWP, acc1, acc0, nextw.y, d + 16)) update(acc0, tile * BFM_TR + 4 * h);
         __syncthreads();
     }
+#pragma unroll
+    for (int b = 0; b < BFM_QB; b++) flagged[b] = true;
+    update(acc1, (ntiles - 1) * BFM_TR + 32 + 4 * h);
 #pragma unroll
     for (int b = 0; b < BFM_QB; b++) {
         const long long qi = q0 + b * 32 + c;
@@ -398,14 +482,25 @@ static int bf_chunks(int nq, int64_t nd, int resident, int queriesPerWg, int gro
     return (int)std::max<long long>(1, (nd + rpc - 1) / rpc);
 }
 
-// Scan + per-chunk merge into d_packed, partials in `partial` (room for chunkLimit * nq words).
-static int bf_scan_into(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t* d_packed, unsigned long long* partial,
+// 64-bit words of scratch a scan of nq queries in `chunks` chunks uses: the thresholds the chunks of a query
+// publish to each other (one 32-bit word per query, at the head) and the per-chunk partial results.
+static size_t bf_threshold_words(int nq) { return ((size_t)nq + 1) / 2; }
+static size_t bf_scratch_words(int nq, int chunks) {
+    return bf_threshold_words(nq) + (size_t)BF_PARTS_PER_CHUNK * chunks * nq;
+}
+
+// Scan + per-chunk merge into d_packed; `scratch` has room for bf_scratch_words(nq, chunks).
+static int bf_scan_into(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t* d_packed, unsigned long long* scratch,
                         int chunks, long long rpc, hipStream_t st) {
     const int qBlocks = (nq + BFM_QUERIES_PER_WG - 1) / BFM_QUERIES_PER_WG;
     int parts = BF_PARTS_PER_CHUNK * chunks;
+    unsigned long long* partial = scratch + bf_threshold_words(nq);
     if (bf->n > 0) {
+        // the published thresholds start at "nothing yet"; every partial word is written before the merge reads it
+        HIP_TRY(hipMemsetAsync(scratch, 0, bf_threshold_words(nq) * 8, st));
         hipLaunchKernelGGL(k_bf_mfma, dim3(qBlocks, chunks), dim3(256), BFM_LDS, st, (const uint32_t*)d_q, nq,
-                           (const uint32_t*)bf->d_db, (long long)bf->n, rpc, (long long)bf->globalBase, partial);
+                           (const uint32_t*)bf->d_db, (long long)bf->n, rpc, (long long)bf->globalBase, partial,
+                           (uint32_t*)scratch);
     } else {
         HIP_TRY(hipMemsetAsync(partial, 0xFF, (size_t)nq * 8, st));
         parts = 1;
@@ -429,7 +524,7 @@ extern "C" int orb_bf_query_packed_device(orb_bf* bf, const uint8_t* d_q, int nq
     HIP_TRY(hipSetDevice(bf->device));
     long long rpc = BFM_TR;
     const int chunks = bf_chunks(nq, bf->n, bf->residentBlocks, BFM_QUERIES_PER_WG, BFM_TR, 4096, &rpc);
-    int rc = bf_ensure(bf->d_partial, bf->partialBytes, (size_t)BF_PARTS_PER_CHUNK * chunks * nq * 8);
+    int rc = bf_ensure(bf->d_partial, bf->partialBytes, bf_scratch_words(nq, chunks) * 8);
     if (rc) return rc;
     return bf_scan_into(bf, d_q, nq, d_packed, (unsigned long long*)bf->d_partial, chunks, rpc, (hipStream_t)stream);
 }
@@ -446,11 +541,13 @@ extern "C" int orb_bf_query_packed_noalloc(orb_bf* bf, const uint8_t* d_q, int n
     }
     if (nq == 0) return ORB_OK;
     HIP_TRY(hipSetDevice(bf->device));
-    // as many chunks as the fixed block has room for: ORB_BF_NOALLOC_MAX_QUERIES queries still get 8
+    // as many chunks as the fixed block has room for beside the threshold words: ORB_BF_NOALLOC_MAX_QUERIES
+    // queries still get 7
     long long rpc = BFM_TR;
     const int chunks = bf_chunks(nq, bf->n, bf->residentBlocks, BFM_QUERIES_PER_WG, BFM_TR,
-                                 (long long)(BF_STATIC_WORDS / BF_PARTS_PER_CHUNK / (unsigned)nq), &rpc);
-    // every (chunk, query) word is written by the scan before the merge reads it: nothing to clear between calls
+                                 (long long)((BF_STATIC_WORDS - bf_threshold_words(nq)) / BF_PARTS_PER_CHUNK / (unsigned)nq), &rpc);
+    // the threshold words are cleared on the stream before the scan (no allocation); every (chunk, query) word is
+    // written by the scan before the merge reads it
     return bf_scan_into(bf, d_q, nq, d_packed, bf->d_static, chunks, rpc, (hipStream_t)stream);
 }
 

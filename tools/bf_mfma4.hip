@@ -72,7 +72,9 @@ __global__ void k_expand(const uint32_t* __restrict__ db, long long n, v4i* __re
 
 __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__ q, int nq, const uint32_t* __restrict__ db,
                                                  long long n, long long rowsPerChunk, long long globalBase,
-                                                 unsigned long long* __restrict__ partial) {
+                                                 unsigned long long* __restrict__ partial,
+                                                 unsigned long long* __restrict__ clk) {
+    const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
     extern __shared__ __attribute__((aligned(16))) uint8_t s_rows[];  // two buffers of TR expanded rows
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, h = lane >> 5, c = lane & 31;
     const long long q0 = (long long)blockIdx.x * (4 * QB * 32) + w * (QB * 32);
@@ -207,7 +209,12 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__
             v16f acc[QB];
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
+#ifdef BARE
+                v4i a4 = bq[0][ks];  // (no LDS read: the matrix instructions alone)
+                a4[0] ^= tile << 16;  // (differs per tile, or the loop's products would be computed once)
+#else
                 const v4i a4 = *(const v4i*)(base + rb * 32 * ROWP + ks * 32);
+#endif
                 const v8i a = {a4[0], a4[1], a4[2], a4[3], 0, 0, 0, 0};
 #pragma unroll
                 for (int b = 0; b < QB; b++) {
@@ -260,7 +267,13 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__
 #else
         if (more && tile == 0) stash(buf ^ 1, tile + 1, nextw);
 #endif
+#ifndef BARE
         __syncthreads();
+#endif
+    }
+    if (t == 0) {  // engine clock while the kernel ran: clock64() ticks per 100 MHz wall-clock tick
+        atomicAdd(&clk[0], clock64() - clk0);
+        atomicAdd(&clk[1], wall_clock64() - wall0);
     }
 #pragma unroll
     for (int b = 0; b < QB; b++) {
@@ -274,6 +287,269 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__
         }
     }
 }
+
+// -DPIPE: the same scan with the vector-ALU work placed in the shadow of the matrix instructions.  A matrix
+// instruction keeps the SIMD's issue port for about half of its 32 cycles and leaves room for four vector
+// instructions beside it (tools/mfma_valu_overlap.hip), but only if they are independent and stand next to it in the
+// instruction stream: a wavefront issues in order.  So the tile's two row blocks use two sets of accumulators, and
+// while the 16 matrix instructions of one block run, the top-2 filter of the other block's finished products and the
+// expansion of the next tile's rows are issued between them, two to four at a time (scheduling barriers pin the order);
+// the filter of all four query blocks ends in one branch per row block instead of four.
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef VPM
+#define VPM 4  // vector instructions placed behind each matrix instruction
+#endif
+__global__ __launch_bounds__(256, 2) void k_bf_pipe(const uint32_t* __restrict__ q, int nq, const uint32_t* __restrict__ db,
+                                                 long long n, long long rowsPerChunk, long long globalBase,
+                                                 unsigned long long* __restrict__ partial,
+                                                 unsigned long long* __restrict__ clk) {
+    static_assert(QB == 4 && TR == 64, "the interleaving below is written for four query blocks and two row blocks");
+    const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
+    uint32_t* gthr = (uint32_t*)(clk + 2);  // one word per query, zero before the launch
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_rows[];  // two buffers of TR expanded rows
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, h = lane >> 5, c = lane & 31;
+    const long long q0 = (long long)blockIdx.x * (4 * QB * 32) + w * (QB * 32);
+    const long long r0 = (long long)blockIdx.y * rowsPerChunk;
+    const long long rEnd = std::min(n, r0 + rowsPerChunk);
+    const int rows = (int)(rEnd - r0);
+    if (rows <= 0) return;  // (whole workgroup)
+
+    v4i bq[QB][4];
+#pragma unroll
+    for (int b = 0; b < QB; b++) {
+        const long long qi = q0 + b * 32 + c;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) bq[b][ks] = expand32<true>(qi < nq ? q[qi * 8 + 2 * ks + h] : 0u);
+    }
+    int pcq[QB];
+#pragma unroll
+    for (int b = 0; b < QB; b++) {
+        const long long qi = q0 + b * 32 + c;
+        pcq[b] = 0;
+        if (qi < nq)
+            for (int ks = 0; ks < 8; ks++) pcq[b] += __popc(q[qi * 8 + ks]);
+    }
+    float best[QB], sec[QB];
+    int bidx[QB];
+#pragma unroll
+    for (int b = 0; b < QB; b++) best[b] = sec[b] = SENT, bidx[b] = 0;
+
+    const int srow = t >> 2, swp = t & 3;  // staging: thread = (row, word pair)
+    auto fetch = [&](int tile) -> uint2 {
+        const long long r = r0 + (long long)tile * TR + srow;
+        return r < rEnd ? *(const uint2*)(db + r * 8 + 2 * swp) : uint2{0u, 0u};
+    };
+    // every register of a row block's products, one by one (rare: only when the filter saw a candidate)
+    bool hitB[QB] = {true, true, true, true};  // which query blocks the last filter pass flagged
+    // The two lanes of a query (rows 0-3, 8-11, .. and rows 4-7, 12-15, .. of every block) keep separate lists; the
+    // filter compares with the larger of their second-best values: a product that does not beat it has two earlier
+    // rows at least as good, in one list or the other, and cannot be among the query's two best.
+    float thr[QB];
+#pragma unroll
+    for (int b = 0; b < QB; b++) thr[b] = SENT;
+    auto slow = [&](const v16f* acc, int rowBase) {
+#pragma unroll
+        for (int b = 0; b < QB; b++) {
+            if (__ballot(hitB[b]) == 0ull) continue;
+#ifdef TOURN
+            if (rowBase >= 0 && rowBase + 28 <= rows - 4 * 1) {  // (all 16 rows of both lanes exist: wavefront-uniform test on the block)
+                // the two largest of the sixteen by a tournament on keys 16 * product + (15 - register): the larger key
+                // is the larger product and, among equal products, the earlier row
+                float hi[8], lo[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float k0 = fmaf(acc[b][2 * j], 16.f, (float)(15 - 2 * j)), k1 = fmaf(acc[b][2 * j + 1], 16.f, (float)(14 - 2 * j));
+                    hi[j] = fmaxf(k0, k1);
+                    lo[j] = fminf(k0, k1);
+                }
+#pragma unroll
+                for (int w2 = 4; w2 >= 1; w2 >>= 1) {
+#pragma unroll
+                    for (int j = 0; j < w2; j++) {
+                        const float h1 = hi[j], h2 = hi[j + w2];
+                        hi[j] = fmaxf(h1, h2);
+                        lo[j] = fmaxf(fmaxf(fminf(h1, h2), lo[j]), lo[j + w2]);
+                    }
+                }
+                const float v1 = floorf(hi[0] * 0.0625f), v2 = floorf(lo[0] * 0.0625f);
+                const int slot = 15 - (int)fmaf(v1, -16.f, hi[0]);
+                if (v1 > sec[b]) {
+                    if (v1 > best[b]) {
+                        sec[b] = fmaxf(best[b], v2);
+                        best[b] = v1;
+                        bidx[b] = rowBase + (slot & 3) + 8 * (slot >> 2);
+                    } else {
+                        sec[b] = v1;
+                    }
+                }
+            } else
+#endif
+            {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int r = rowBase + (i & 3) + 8 * (i >> 2);
+                const float v = acc[b][i];
+                if (r < rows && v > sec[b]) {
+                    if (v > best[b]) {
+                        sec[b] = best[b];
+                        best[b] = v;
+                        bidx[b] = r;
+                    } else {
+                        sec[b] = v;
+                    }
+                }
+            }
+            }
+            const float own = fmaxf(sec[b], __shfl_xor(sec[b], 32));
+            thr[b] = fmaxf(thr[b], own);
+#ifdef GTHR
+            const long long qi = q0 + b * 32 + c;
+            if (h == 0 && qi < nq && own > -1000.f) atomicMax(&gthr[qi], __float_as_uint(own + 1024.f));
+#endif
+        }
+    };
+    // 16 matrix instructions (row block at aBase -> accW) with the filter of accR and the expansion of one word of the
+    // next tile between them; returns whether any lane of the wavefront has a candidate in accR
+    auto half = [&](const uint8_t* aBase, v16f* accW, const v16f* accR, uint32_t word, uint8_t* dst, bool doStash) -> bool {
+        v4i aK[4];  // the row block's four k-steps, all requested before the first matrix instruction
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) aK[ks] = *(const v4i*)(aBase + ks * 32);
+        float mm[5], mA = 0.f;
+        bool hit = false;
+        uint32_t ex = 0u;
+        v4i o = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int ks = j >> 2, b = j & 3;
+            const v4i a4 = aK[ks];
+            const v8i a = {a4[0], a4[1], a4[2], a4[3], 0, 0, 0, 0};
+            const v8i bb = {bq[b][ks][0], bq[b][ks][1], bq[b][ks][2], bq[b][ks][3], 0, 0, 0, 0};
+            if (ks == 0) {
+                const v16f zero = {};
+                accW[b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, zero, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            } else {
+                accW[b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, accW[b], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            }
+            const int eb = j >> 2, p = j & 3;  // filter: query block eb, quarter p; expansion: byte eb of the word
+            const v16f s = accR[eb];
+#define MAX3(a, b, c) fmaxf(fmaxf(a, b), c)
+#ifndef P_NOFILT
+            if (p == 0) {
+                mm[0] = MAX3(s[0], s[1], s[2]);
+                mm[1] = MAX3(s[3], s[4], s[5]);
+            } else if (p == 1) {
+                mm[2] = MAX3(s[6], s[7], s[8]);
+                mm[3] = MAX3(s[9], s[10], s[11]);
+            } else if (p == 2) {
+                mm[4] = MAX3(s[12], s[13], s[14]);
+                mA = MAX3(mm[0], mm[1], mm[2]);
+            } else {
+                const float m = fmaxf(mA, MAX3(mm[3], mm[4], s[15]));
+#ifdef P_NOSLOW
+                hitB[eb] = m > thr[eb] + 1e9f;  // (timing only: the list updates never run)
+#else
+                hitB[eb] = m > thr[eb];
+#endif
+                hit |= hitB[eb];
+            }
+#else
+            if (j == 15) hit |= s[0] > sec[eb] + 1e9f;
+#endif
+#ifndef P_NOEXP
+            if (p == 0) {
+                ex = (word >> (8 * eb)) & 255u;
+                ex |= ex << 6;
+            } else if (p == 1) {
+                ex |= ex << 12;
+            } else if (p == 2) {
+                ex &= 0x03030303u;
+            } else {
+                o[eb] = (int)__builtin_amdgcn_perm(0u, 0x22200200u, ex);
+            }
+#else
+            if (j == 0) o[0] = (int)word;
+#endif
+#undef MAX3
+        }
+        // the order the scheduler is to build from the block: the operand reads, then one matrix instruction and up
+        // to four vector ones in turn
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+        }
+        (void)doStash;
+        *(v4i*)dst = o;  // (past the last tile: rows that are never read)
+        return __ballot(hit) != 0ull;
+    };
+
+    const int ntiles = (rows + TR - 1) / TR;
+    {
+        const uint2 w0 = fetch(0);
+        uint8_t* d = s_rows + srow * ROWP + swp * 32;
+        *(v4i*)(d + 0) = expand32<false>(w0.x);
+        *(v4i*)(d + 16) = expand32<false>(w0.y);
+    }
+    uint2 ring = fetch(1);
+    __syncthreads();
+    v16f acc0[QB], acc1[QB];
+#pragma unroll
+    for (int b = 0; b < QB; b++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc1[b][i] = SENT;  // (the first filter pass looks at these)
+    for (int tile = 0; tile < ntiles; tile++) {
+#ifdef GTHR
+        // The chunks of a query run side by side and tell each other their second-best products (biased to be
+        // positive, so that the bit patterns order like the values): a product below another chunk's second best
+        // cannot be among the query's two best; one equal to it still can (it may be the earlier row), hence - 0.5.
+        if ((tile & (GTHR - 1)) == GTHR - 1) {
+#pragma unroll
+            for (int b = 0; b < QB; b++) {
+                const long long qi = q0 + b * 32 + c;
+                if (qi < nq) {
+                    const uint32_t g = __hip_atomic_load(&gthr[qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (g != 0u) thr[b] = fmaxf(thr[b], __uint_as_float(g) - 1024.5f);
+                }
+            }
+        }
+#endif
+        const int buf = tile & 1;
+        const bool more = tile + 1 < ntiles;
+        const uint2 nextw = ring;
+        ring = fetch(tile + 2);
+        const uint8_t* base = s_rows + buf * (TR * ROWP) + c * ROWP + h * 16;
+        uint8_t* d = s_rows + (buf ^ 1) * (TR * ROWP) + srow * ROWP + swp * 32;
+        SB();
+        if (half(base, acc0, acc1, nextw.x, d, more)) slow(acc1, (tile - 1) * TR + 32 + 4 * h);
+        SB();
+        if (half(base + 32 * ROWP, acc1, acc0, nextw.y, d + 16, more)) slow(acc0, tile * TR + 4 * h);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int b = 0; b < QB; b++) hitB[b] = true;
+    slow(acc1, (ntiles - 1) * TR + 32 + 4 * h);
+    if (t == 0) {
+        atomicAdd(&clk[0], clock64() - clk0);
+        atomicAdd(&clk[1], wall_clock64() - wall0);
+    }
+#pragma unroll
+    for (int b = 0; b < QB; b++) {
+        const long long qi = q0 + b * 32 + c;
+        if (qi < nq) {
+            const unsigned long long bd = best[b] == SENT ? 0xFFFFull : (unsigned long long)(pcq[b] - (int)best[b]);
+            const unsigned long long sd = sec[b] == SENT ? 0xFFFFull : (unsigned long long)(pcq[b] - (int)sec[b]);
+            const unsigned long long idx =
+                best[b] == SENT ? 0xFFFFFFFFull : (unsigned long long)(globalBase + r0 + bidx[b]) & 0xFFFFFFFFull;
+            partial[((long long)blockIdx.y * 2 + h) * nq + qi] = (bd << 48) | (sd << 32) | idx;
+        }
+    }
+}
+#ifdef PIPE
+#define SCAN_KERNEL k_bf_pipe
+#else
+#define SCAN_KERNEL k_bf_mfma
+#endif
 
 static uint64_t rng_state = 88172645463325252ull;
 static uint64_t rnd() {
@@ -302,7 +578,8 @@ int main(int argc, char** argv) {
         q[k] = db[(size_t)7 * 8 + k];
     }
     uint32_t *dDb, *dQ;
-    unsigned long long* dPart;
+    unsigned long long *dPart, *dClk;
+    CHECK(hipMalloc((void**)&dClk, 16 + (size_t)nq * 4));
     CHECK(hipMalloc((void**)&dDb, db.size() * 4));
     CHECK(hipMalloc((void**)&dQ, q.size() * 4));
     CHECK(hipMemcpy(dDb, db.data(), db.size() * 4, hipMemcpyHostToDevice));
@@ -327,18 +604,22 @@ int main(int argc, char** argv) {
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     float best = 1e30f;
+    unsigned long long clk[2] = {0, 0};
     for (int r = 0; r < reps + 1; r++) {
+        CHECK(hipMemset(dClk, 0, 16 + (size_t)nq * 4));
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL(k_bf_mfma, dim3(qGroups, chunks), dim3(256), lds, 0, dQ, nq, dScan, n, rpc, 0ll, dPart);
+        hipLaunchKernelGGL(SCAN_KERNEL, dim3(qGroups, chunks), dim3(256), lds, 0, dQ, nq, dScan, n, rpc, 0ll, dPart, dClk);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms;
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         if (r > 0) best = std::min(best, ms);
+        CHECK(hipMemcpy(clk, dClk, 16, hipMemcpyDeviceToHost));
     }
     CHECK(hipGetLastError());
-    printf("QB %d TR %d: %lld rows x %d queries, %d x %d workgroups: %.3f ms = %.0f Gcmp/s\n", QB, TR, n, nq, qGroups, chunks, best,
-           (double)n * nq / (best * 1e-3) / 1e9);
+    const double mhz = clk[1] ? 100.0 * (double)clk[0] / (double)clk[1] : 0.0;
+    printf("QB %d TR %d: %lld rows x %d queries, %d x %d workgroups: %.3f ms = %.0f Gcmp/s, clock64 at %.0f MHz (%.1f M cycles)\n", QB, TR,
+           n, nq, qGroups, chunks, best, (double)n * nq / (best * 1e-3) / 1e9, mhz, best * 1e-3 * mhz);
     std::vector<unsigned long long> part((size_t)2 * chunks * nq);
     CHECK(hipMemcpy(part.data(), dPart, part.size() * 8, hipMemcpyDeviceToHost));
     int bad = 0;
