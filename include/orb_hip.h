@@ -312,9 +312,10 @@ int orb_bf_query_packed_device(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t*
 /* orb_bf_query_packed_device for callers that cannot allocate device memory
  * (code under HIP graph capture, tight serving loops, harnesses that forbid
  * it).  No counterpart in the reference.  Same arguments and result, but the
- * per-chunk partial results live in a fixed 32 MiB block inside the library's
- * device image instead of a buffer grown on demand, and the call makes no
- * hipMalloc / hipFree.  At most ORB_BF_NOALLOC_MAX_QUERIES queries per call
+ * per-chunk partial results (and the one word per query through which the
+ * chunks tell each other their thresholds, cleared on `stream` by the call)
+ * live in a fixed 32 MiB block inside the library's device image instead of a
+ * buffer grown on demand, and the call makes no hipMalloc / hipFree.  At most ORB_BF_NOALLOC_MAX_QUERIES queries per call
  * (more: ORB_ERR_CAPACITY, nothing is launched).  All calls on one device share
  * the block: calls that overlap in time on the same device race, whichever
  * handles or streams they use. */
