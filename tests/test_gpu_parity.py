@@ -493,6 +493,41 @@ def test_brute_force_random_shapes(hip, oracle):
     bf.close()
 
 
+def test_brute_force_chunks_share_thresholds(hip, oracle):
+    """The chunks of a query run side by side and raise each other's thresholds: a database cut into many chunks
+    (512 queries over 400 000 rows: 48 chunks of 130 tiles, so every workgroup reads the published thresholds several
+    times), with each query's best row copied into other chunks (the lowest row number has to win whichever chunk
+    finds its copy first), near copies before and after it (second best equal to or one above the best, in another
+    chunk), and queries without any close row.  Three runs: what a chunk sees of the others depends on timing, the
+    result must not."""
+    rng = np.random.default_rng(4242)
+    nd, nq = 400000, 512
+    db = rng.integers(0, 256, (nd, 32), dtype=np.uint8)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    for k in range(384):
+        home = int(rng.integers(0, nd))
+        q[k] = db[home]
+        if k % 4 != 3:  # exact copies elsewhere: ties for the best
+            for _ in range(1 + k % 3):
+                db[int(rng.integers(0, nd))] = db[home]
+        if k % 2 == 0:  # near copies: one to three bits off
+            for _ in range(1 + k % 2):
+                r = int(rng.integers(0, nd))
+                db[r] = db[home]
+                for _ in range(int(rng.integers(1, 4))):
+                    db[r, int(rng.integers(0, 32))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+    io, bo, so = oracle.bf_top2(q, db)
+    bf = hip.BruteForce(0)
+    bf.set_database(db)
+    for run in range(3):
+        ig, bg, sg = bf.query_top2(q)
+        np.testing.assert_array_equal(ig, io, err_msg="run %d" % run)
+        np.testing.assert_array_equal(bg, bo)
+        np.testing.assert_array_equal(sg, so)
+    assert (bo[:384] == 0).sum() > 370 and (so[:384] <= 3).sum() > 200  # (a planted row now and then overwrites another)
+    bf.close()
+
+
 def test_brute_force_sharded_merge(hip, oracle):
     """Row shards on one device, packed per-shard results merged by the merge
     kernel: equals the scan of the whole database (the all-gather only moves
