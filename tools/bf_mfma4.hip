@@ -1,11 +1,22 @@
-// Development prototype (FP4 form): brute-force Hamming top-2 on the matrix cores.  Build-time switches for
-// measurements: -DNO_LDS / -DNO_EXPAND / -DNO_EPI drop the operand reads, the row expansion, the top-2 filter (shares
-// of the run time); -DPREX scans a database expanded once in global memory; -DPD=n lets the global loads run n tiles
-// ahead; -DWIDE accumulates all row blocks of a tile before any is looked at; -DUSE_LUT expands through a table in LDS.
-// None of PREX, PD, WIDE, USE_LUT changed the rate by more than 2 %.  Descriptor bits become bytes +1 / -1, so
-// that the dot product of two descriptors is 256 - 2 * (Hamming distance); v_mfma_i32_32x32x32_i8 then makes 32 rows
-// x 32 queries x 32 bits per instruction.  Stand-alone: generates data, runs the kernel, checks a sample of queries
-// against a CPU scan, prints Gcmp/s.  Build: hipcc --offload-arch=gfx950 -O3 tools/bf_mfma.hip -o tools/bf_mfma
+// Development prototype (FP4 form): brute-force Hamming top-2 on the matrix cores.  Query bits become the FP4 values
+// +1 / -1, database bits 1 / 0, so that the dot product of a row and a query is popcount(query) - distance;
+// v_mfma_scale_f32_32x32x64_f8f6f4 makes 32 rows x 32 queries x 64 bits per instruction.  Stand-alone: generates
+// data, runs the kernel, checks a sample of queries against a CPU scan, prints Gcmp/s, the engine clock during the
+// launch (clock64 / wall_clock64) and the launch in engine cycles.
+//   tools/bf_mfma4 <rows> <queries> <repetitions> [workgroups to aim for]
+// Two kernels.  k_bf_mfma: every row block's products are filtered right after its matrix instructions (the
+// library's kernel until the interleaved one).  Switches for measurements: -DNO_EXPAND / -DNO_EPI drop the row
+// expansion / the top-2 filter (shares of the run time), -DBARE also the LDS operand reads and the barrier (the
+// matrix instructions alone), -DPREX scans a database expanded once in global memory, -DPD=n lets the global loads
+// run n tiles ahead, -DWIDE accumulates all row blocks of a tile before any is looked at, -DUSE_LUT expands
+// through a table in LDS, -DPERM expands through v_perm_b32 (the library's form).  None of PREX, PD, WIDE, USE_LUT
+// changed the rate by more than 2 %.
+// k_bf_pipe (-DPIPE): the library's kernel -- filter and expansion issued between the matrix instructions, list
+// updates per query block, thresholds shared by the two lanes of a query and, with -DGTHR=n (refresh every n tiles),
+// by the chunks of a query.  -DP_NOFILT / -DP_NOEXP / -DP_NOSLOW take the filter, the expansion, the list updates
+// out (timing only: results are wrong), -DTOURN updates the lists through a tournament on keys (no gain: it spills).
+// Build: hipcc --offload-arch=gfx950 -O3 -fno-honor-nans -mllvm -disable-machine-sink -DPERM -DPIPE -DGTHR=32
+//        tools/bf_mfma4.hip -o tools/bf_mfma4
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
