@@ -28,11 +28,14 @@
 // plus a 3-pixel halo (plus up to 3 bytes of alignment slack per row and one spare row that the
 // two-rows-per-step walk may touch), the score tile the interior plus a zero rim.  Two instances: cells up
 // to 37 x 35 (every level of the usual frame sizes) and the general one up to 59 x 59.
+// A level belongs to the instance its largest cell fits (OrbLevel::fastClass, set by the host); a frame size whose
+// coarse levels have tall cells still runs its many fine-level cells on the small instance.
 struct TileSmall {
-    static constexpr int TILE_PITCH = 48, TILE_ROWS = 42, SCORE_PITCH = 40, SCORE_ROWS = 37, MAX_W = 37, MAX_H = 35, WAVES_PER_SIMD = 8;
+    static constexpr int TILE_PITCH = 48, TILE_ROWS = 42, SCORE_PITCH = 40, SCORE_ROWS = 37, MAX_W = ORB_FAST_SMALL_W, MAX_H = ORB_FAST_SMALL_H,
+                         WAVES_PER_SIMD = 8, CLASS = 0;
 };
 struct TileLarge {
-    static constexpr int TILE_PITCH = 72, TILE_ROWS = 66, SCORE_PITCH = 64, SCORE_ROWS = 62, MAX_W = 59, MAX_H = 59, WAVES_PER_SIMD = 4;
+    static constexpr int TILE_PITCH = 72, TILE_ROWS = 66, SCORE_PITCH = 64, SCORE_ROWS = 62, MAX_W = 59, MAX_H = 59, WAVES_PER_SIMD = 4, CLASS = 1;
 };
 #define CORN_CAP 256                                    // corners listed per cell for the suppression pass
 
@@ -159,16 +162,16 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
     static_assert(FAST_WAVES == 1, "the cell numbering assumes one wavefront per workgroup");
     const int cellsPerFrame = g->cellsPerFrame;
     int frameLocal;
-    unsigned cellU;
-    if (!orb_xcd_map(blockIdx.x, (unsigned)cellsPerFrame, g->cellsPerFrameMagic, nframes, &frameLocal, &cellU)) return;
+    unsigned cellU;  // the cell's number among the frame's cells of this instance's class
+    if (!orb_xcd_map(blockIdx.x, (unsigned)g->fastCells[TG::CLASS], g->fastCellsMagic[TG::CLASS], nframes, &frameLocal, &cellU)) return;
     const int frame = frame0 + frameLocal;
-    const int c = (int)cellU;
-    const int64_t cellGlobal = (int64_t)frame * cellsPerFrame + c;
-    int level = 0;
-    for (int l = 1; l < g->nlevels; l++)
-        if (c >= g->lv[l].cellBase) level = l;
+    int level = g->fastFirst[TG::CLASS];
+    for (int l = level + 1; l < g->nlevels; l++)
+        if (g->lv[l].fastClass == TG::CLASS && (int)cellU >= g->lv[l].classBase) level = l;
     const OrbLevel& L = g->lv[level];
-    const int ci = c - L.cellBase;
+    const int ci = (int)cellU - L.classBase;
+    const int c = L.cellBase + ci;
+    const int64_t cellGlobal = (int64_t)frame * cellsPerFrame + c;
     const int i = (int)orb_div((unsigned)ci, (unsigned)L.nCols, L.nColsMagic), j = ci - i * L.nCols;
 
     // Cell ROI and interior, src/ORBextractor.cc:825-844 (note the 3 / 6 asymmetry of the skip tests).
@@ -355,16 +358,15 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
 
 int orb_launch_fast(const OrbBatch& b) {
     const OrbGeom& g = *b.h_geom;
-    const int64_t blocks = orb_xcd_grid(b.nframes, g.cellsPerFrame);
     // (orb_api.hip refuses geometries whose cells exceed 59 x 59 before anything is launched)
-    if (g.maxCellW <= TileSmall::MAX_W && g.maxCellH <= TileSmall::MAX_H)
-        hipLaunchKernelGGL(k_fast_cells<TileSmall>, dim3((unsigned)blocks), dim3(64 * FAST_WAVES), 0, (hipStream_t)b.stream,
-                           b.d_geom, b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, b.nframes, b.d_cellKeys,
-                           b.d_cellCount);
-    else
-        hipLaunchKernelGGL(k_fast_cells<TileLarge>, dim3((unsigned)blocks), dim3(64 * FAST_WAVES), 0, (hipStream_t)b.stream,
-                           b.d_geom, b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, b.nframes, b.d_cellKeys,
-                           b.d_cellCount);
+    if (g.fastCells[0] > 0)
+        hipLaunchKernelGGL(k_fast_cells<TileSmall>, dim3((unsigned)orb_xcd_grid(b.nframes, g.fastCells[0])), dim3(64 * FAST_WAVES), 0,
+                           (hipStream_t)b.stream, b.d_geom, b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, b.nframes,
+                           b.d_cellKeys, b.d_cellCount);
+    if (g.fastCells[1] > 0)
+        hipLaunchKernelGGL(k_fast_cells<TileLarge>, dim3((unsigned)orb_xcd_grid(b.nframes, g.fastCells[1])), dim3(64 * FAST_WAVES), 0,
+                           (hipStream_t)b.stream, b.d_geom, b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, b.nframes,
+                           b.d_cellKeys, b.d_cellCount);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         orb_set_error("fast launch failed: %s", hipGetErrorString(e));

@@ -394,6 +394,7 @@ static int compute_geom(orb_ctx* c, int w, int h) {
     std::vector<OrbLinTap> lt;
     int64_t pyrOff = 0;
     int cellBase = 0, outBase = 0, cellCap = 1;
+    int fastCells[2] = {0, 0};
     int64_t keyBase = 0, nodeBase = 0;
     for (int l = 0; l < p.nlevels; l++) {
         OrbLevel& L = g.lv[l];
@@ -439,6 +440,7 @@ static int compute_geom(orb_ctx* c, int w, int h) {
         nodeBase += L.nodeCap;
         // most keys FAST can emit: strict local maxima take at most one pixel of every 2x2 block of a cell interior
         int64_t keys = 0;
+        int levelCellW = 0, levelCellH = 0;
         for (int i = 0; i < L.nRows; i++) {
             const int iniY = ORB_BORDER + i * L.hCell;
             if (iniY >= L.maxBorderY - 3) continue;
@@ -454,6 +456,8 @@ static int compute_geom(orb_ctx* c, int w, int h) {
                 const int cap = halfUp(cw) * halfUp(ch);
                 g.maxCellW = std::max(g.maxCellW, cw);
                 g.maxCellH = std::max(g.maxCellH, ch);
+                levelCellW = std::max(levelCellW, cw);
+                levelCellH = std::max(levelCellH, ch);
                 keys += cap;
                 cellCap = std::max(cellCap, cap);
             }
@@ -462,6 +466,10 @@ static int compute_geom(orb_ctx* c, int w, int h) {
             orb_set_error("frame too large");
             return ORB_ERR_UNSUPPORTED;
         }
+        // the FAST kernel's two instances: a level whose cells fit the small tile runs at twice the occupancy
+        L.fastClass = (levelCellW <= ORB_FAST_SMALL_W && levelCellH <= ORB_FAST_SMALL_H) ? 0 : 1;
+        L.classBase = fastCells[L.fastClass];
+        fastCells[L.fastClass] += L.nCols * L.nRows;
         L.keyCap = (int)keys;
         L.keyBase = keyBase;
         keyBase += keys;
@@ -530,6 +538,13 @@ static int compute_geom(orb_ctx* c, int w, int h) {
     for (int l = 0; l < g.nlevels; l++)
         maxRank = std::max<uint64_t>(maxRank, (uint64_t)g.lv[l].nCols * g.lv[l].nRows * cellCap);
     g.cellsPerFrameMagic = orb_div_magic((uint32_t)cellBase, framesPerLane * cellBase);
+    for (int cls = 0; cls < 2; cls++) {
+        g.fastCells[cls] = fastCells[cls];
+        g.fastCellsMagic[cls] = orb_div_magic((uint32_t)fastCells[cls], framesPerLane * fastCells[cls]);
+        g.fastFirst[cls] = -1;
+        for (int l = g.nlevels - 1; l >= 0; l--)
+            if (g.lv[l].fastClass == cls) g.fastFirst[cls] = l;
+    }
     g.outCapFrameMagic = orb_div_magic((uint32_t)outBase, framesPerLane * outBase);
     g.cellCapMagic = orb_div_magic((uint32_t)cellCap, maxRank);
     g.keysPerFrame = keyBase;

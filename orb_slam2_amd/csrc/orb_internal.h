@@ -11,6 +11,8 @@
 #define ORB_MAX_TAPS 4          // source cells one destination pixel of the area resize may cover per axis
 #define ORB_EDGE 19             // EDGE_THRESHOLD, src/ORBextractor.cc:21
 #define ORB_BORDER 16           // EDGE_THRESHOLD - 3, src/ORBextractor.cc:808
+#define ORB_FAST_SMALL_W 37      // largest cell interior the FAST kernel's small-tile instance holds
+#define ORB_FAST_SMALL_H 35
 #define ORB_CELL_MAX 64         // a FAST cell interior is at most 59 pixels wide / high
 #define ORB_CODE_DEPTH 14       // quadtree path digits kept per key (2 bits each) + 4 bits initial node
 #define ORB_GRID_COLS 64        // include/Frame.h:17
@@ -27,6 +29,8 @@ struct OrbLevel {
     unsigned nColsMagic;             // orb_div_magic(nCols)
     int maxBorderX, maxBorderY;
     int cellBase;               // index of the level's first cell within a frame
+    int fastClass, classBase;   // FAST kernel instance the level's cells fit (0: small tile, 1: large), index of
+                                // the level's first cell among the frame's cells of that class
     int nIni;                   // quadtree initial nodes, src/ORBextractor.cc:574
     float hX;                   // :576
     int quota;                  // mnFeaturesPerLevel[level]
@@ -49,6 +53,8 @@ struct OrbGeom {
     int cellsPerFrame, cellCap;   // cellCap: key slots per cell
     unsigned cellsPerFrameMagic, outCapFrameMagic, cellCapMagic;  // orb_div_magic of cellsPerFrame, outCapFrame, cellCap
     int maxCellW, maxCellH;       // largest FAST cell interior over all levels
+    int fastCells[2], fastFirst[2];  // per FAST kernel instance: cells per frame, first level of the class (-1: none)
+    unsigned fastCellsMagic[2];      // orb_div_magic of fastCells
     int areaTapsMax;              // most source cells any area-resize tap entry of the pyramid uses (per axis)
     int outCapFrame;              // sum of outCap
     int64_t keysPerFrame;         // sum of keyCap
