@@ -133,7 +133,7 @@ static __device__ __forceinline__ bfm_v4i bfm_expand32(uint32_t bits) {
 __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__ q, int nq, const uint32_t* __restrict__ db,
                                                     long long n, long long rowsPerChunk, long long globalBase,
                                                     unsigned long long* __restrict__ partial,
-                                                    uint32_t* __restrict__ shared) {
+                                                    uint32_t* __restrict__ shared) {  // (null: a single chunk)
     static_assert(BFM_QB == 4 && BFM_TR == 64, "the interleaving is written for four query blocks and two row blocks");
     extern __shared__ __attribute__((aligned(16))) uint8_t s_rows[];  // two buffers of BFM_TR expanded rows
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, h = lane >> 5, c = lane & 31;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__
             const float own = fmaxf(sec[b], __shfl_xor(sec[b], 32));
             thr[b] = fmaxf(thr[b], own);
             const long long qi = q0 + b * 32 + c;
-            if (h == 0 && qi < nq && own > -BFM_BIAS) atomicMax(&shared[qi], __float_as_uint(own + BFM_BIAS));
+            if (shared && h == 0 && qi < nq && own > -BFM_BIAS) atomicMax(&shared[qi], __float_as_uint(own + BFM_BIAS));
         }
     };
 
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__
 #pragma unroll
         for (int i = 0; i < 16; i++) acc1[b][i] = BFM_NONE;  // (what the first filter pass looks at)
     for (int tile = 0; tile < ntiles; tile++) {
-        if ((tile & (BFM_REFRESH - 1)) == BFM_REFRESH - 1) {
+        if (shared && (tile & (BFM_REFRESH - 1)) == BFM_REFRESH - 1) {
 #pragma unroll
             for (int b = 0; b < BFM_QB; b++) {
                 const long long qi = q0 + b * 32 + c;
@@ -496,11 +496,12 @@ static int bf_scan_into(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t* d_pack
     int parts = BF_PARTS_PER_CHUNK * chunks;
     unsigned long long* partial = scratch + bf_threshold_words(nq);
     if (bf->n > 0) {
-        // the published thresholds start at "nothing yet"; every partial word is written before the merge reads it
-        HIP_TRY(hipMemsetAsync(scratch, 0, bf_threshold_words(nq) * 8, st));
+        // the published thresholds start at "nothing yet" (a single chunk has nobody to tell: no words, no clearing);
+        // every partial word is written before the merge reads it
+        uint32_t* shared = chunks > 1 ? (uint32_t*)scratch : nullptr;
+        if (shared) HIP_TRY(hipMemsetAsync(shared, 0, bf_threshold_words(nq) * 8, st));
         hipLaunchKernelGGL(k_bf_mfma, dim3(qBlocks, chunks), dim3(256), BFM_LDS, st, (const uint32_t*)d_q, nq,
-                           (const uint32_t*)bf->d_db, (long long)bf->n, rpc, (long long)bf->globalBase, partial,
-                           (uint32_t*)scratch);
+                           (const uint32_t*)bf->d_db, (long long)bf->n, rpc, (long long)bf->globalBase, partial, shared);
     } else {
         HIP_TRY(hipMemsetAsync(partial, 0xFF, (size_t)nq * 8, st));
         parts = 1;
