@@ -364,11 +364,20 @@ static QtLaunch qt_plan(const OrbGeom& g, bool bigFrames, int pass) {
     return q;
 }
 
+// More (frame, level) pairs than the chip holds workgroups of at once (768 with the full-depth histograms)?
+// ORBHIP_QT_TWO_PASS_MIN moves the threshold (tests).
+static bool qt_large_launch(int pairs) {
+    const char* e = getenv("ORBHIP_QT_TWO_PASS_MIN");
+    return pairs >= (e ? atoi(e) : 768);
+}
+
 static int qt_launch(const OrbBatch& b, bool bigFrames, int pass) {
     const OrbGeom& g = *b.h_geom;
     // (a few frames: twice the threads shorten the counting pass of the one workgroup everything waits for,
-    // level 0's, 39 -> 35 us; four times gain nothing more)
-    const int threads = bigFrames ? 1024 : (b.nframes < ORB_FEW_FRAMES ? 512 : 256);
+    // level 0's, 39 -> 35 us; four times gain nothing more.  A launch with more workgroups than the chip holds is
+    // the opposite case: most of a level's distribution runs on a few dozen threads, so half the threads per
+    // workgroup and twice the workgroups per CU do more: 0.148 -> 0.128 ms at 512 frames, 64 threads no better.)
+    const int threads = bigFrames ? 1024 : b.nframes < ORB_FEW_FRAMES ? 512 : qt_large_launch(b.nframes * g.nlevels) ? 128 : 256;
     QtLaunch q = qt_plan(g, bigFrames, pass);
     q.nframesMagic = orb_div_magic((uint32_t)b.nframes, (uint64_t)b.nframes * q.nlevels);
     const size_t lds = (size_t)q.ldsKeys * 8 + (size_t)q.regionInts * 4;
@@ -409,12 +418,10 @@ static int qt_launch(const OrbBatch& b, bool bigFrames, int pass) {
 }
 
 // A large batch is bound by how many workgroups a CU holds, a smaller one (all of whose workgroups are resident at
-// once anyway: 768 with the full-depth histograms) by the latency of one workgroup: two passes when the first one's
-// smaller histograms make a difference to the former.  ORBHIP_QT_TWO_PASS_MIN moves the threshold (tests).
+// once anyway) by the latency of one workgroup: two passes when the first one's smaller histograms make a
+// difference to the former.
 bool orb_quadtree_two_passes(const OrbGeom& g, int nframes) {
-    const char* e = getenv("ORBHIP_QT_TWO_PASS_MIN");
-    const int least = e ? atoi(e) : 768;
-    if (g.lv[0].keyCap > ORB_QT_BIG_KEYCAP || nframes * g.nlevels < least) return false;
+    if (g.lv[0].keyCap > ORB_QT_BIG_KEYCAP || !qt_large_launch(nframes * g.nlevels)) return false;
     for (int l = 0; l < g.nlevels; l++)
         if (g.lv[l].histDepthFirst < g.lv[l].histDepth) return true;
     return false;

@@ -40,7 +40,7 @@ static inline int qt_host_fetch_add(int* p, int v) {
 #define QT_BARRIER() __syncthreads()
 #define QT_TID ((int)threadIdx.x)
 #define QT_NT ((int)blockDim.x)
-#define QT_NT_SHIFT (blockDim.x == 1024 ? 10 : 8)  // the kernel runs with 256 or 1024 threads: a shift, not a division
+#define QT_NT_SHIFT (31 - __clz((int)blockDim.x))  // the kernel runs with a power of two of threads: a shift, not a division
 #define QT_FDIV(a, b) __fdiv_rn((a), (b))
 #define QT_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #define QT_ATOMIC_MAX32(p, v) atomicMax((p), (v))
