@@ -291,6 +291,24 @@ __global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ src, 
     }
 }
 
+// Frames whose rows do not start on 4-byte boundaries (a 1241-pixel-wide frame stored without padding) would send
+// every kernel that stages level 0 down its byte-by-byte path; they are copied once into rows of an aligned
+// pitch instead.  Thread = four destination bytes of one row.
+__global__ __launch_bounds__(256) void k_realign_rows(const uint8_t* __restrict__ src, int w, int sstride, int64_t sFrame,
+                                                      uint8_t* __restrict__ dst, int dpitch, int64_t dFrame, int rowsPerFrame,
+                                                      int blocksPerRow) {
+    const int row = blockIdx.x / blocksPerRow;  // over all frames
+    const int x = 4 * ((blockIdx.x - row * blocksPerRow) * 256 + threadIdx.x);
+    if (x >= w) return;
+    const int frame = row / rowsPerFrame, y = row - frame * rowsPerFrame;
+    const uint8_t* p = src + frame * sFrame + (int64_t)y * sstride + x;
+    uint32_t v = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (x + i < w) v |= (uint32_t)p[i] << (8 * i);
+    *(uint32_t*)(dst + frame * dFrame + (int64_t)y * dpitch + x) = v;
+}
+
 static int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -456,6 +474,15 @@ static int launch_pyramid_few(const OrbBatch& b) {
         hipLaunchKernelGGL((k_pyramid_few<false, 2>), grid, dim3(PF_THREADS), (size_t)g.chainLds, (hipStream_t)b.stream, b.d_geom,
                            b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, (const void*)b.d_linTaps, bufBytes);
     return check_launch("pyramid");
+}
+
+int orb_launch_realign(const uint8_t* src, int w, int h, int sstride, int64_t sFrame, uint8_t* dst, int dpitch, int n,
+                       void* stream) {
+    // (dpitch is a multiple of 64 and at least w: the last dword of a row lies inside it)
+    const int blocksPerRow = (w + 1023) / 1024;
+    hipLaunchKernelGGL(k_realign_rows, dim3((unsigned)((int64_t)n * h * blocksPerRow)), dim3(256), 0, (hipStream_t)stream, src, w,
+                       sstride, sFrame, dst, dpitch, (int64_t)dpitch * h, h, blocksPerRow);
+    return check_launch("row realignment");
 }
 
 int orb_launch_pyramid(const OrbBatch& b) {

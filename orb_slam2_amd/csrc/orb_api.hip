@@ -765,6 +765,21 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
     if ((rc = compute_geom(c, w, h))) return rc;
     if ((rc = ensure_buffers(c, n))) return rc;
     if ((rc = finalize_geom_for_batch(c, n))) return rc;
+    c->lastImg0 = d_img0;
+    c->lastStride0 = stride;
+    c->lastFrameStride0 = frameStride;
+    // rows that do not start on 4-byte boundaries: one copy into the context's aligned input block (sized at
+    // orb_create for the largest batch), which every stage then reads with whole dwords
+    if (((unsigned long long)d_img0 | (unsigned long long)stride | (unsigned long long)frameStride) & 3ull) {
+        if ((int64_t)n * h * ((w + 1023) / 1024) > 0x7fffffff) {
+            orb_set_error("batch too large for the row realignment");
+            return ORB_ERR_UNSUPPORTED;
+        }
+        if ((rc = orb_launch_realign(d_img0, w, h, stride, frameStride, (uint8_t*)c->dInput.p, c->inputStride, n, st))) return rc;
+        d_img0 = (const uint8_t*)c->dInput.p;
+        stride = c->inputStride;
+        frameStride = (int64_t)c->inputStride * h;
+    }
     OrbBatch b;
     memset(&b, 0, sizeof(b));
     b.d_geom = (const OrbGeom*)c->dGeom.p;
@@ -795,9 +810,6 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
     b.capPerFrame = cap;
     b.d_nOut = d_nOut;
     b.stream = st;
-    c->lastImg0 = d_img0;
-    c->lastStride0 = stride;
-    c->lastFrameStride0 = frameStride;
     if (c->timing) {  // stage timing: the whole batch as one group, stages back to back on the caller's stream
         hipEvent_t* ev = &c->events[(size_t)(c->evCount % ORB_EV_RING) * 5];
         c->evCount++;

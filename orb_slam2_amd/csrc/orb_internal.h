@@ -218,6 +218,8 @@ struct OrbBatch {  // everything one extraction launch sequence needs
 };
 
 int orb_launch_pyramid(const OrbBatch& b);
+int orb_launch_realign(const uint8_t* src, int w, int h, int sstride, int64_t sFrame, uint8_t* dst, int dpitch, int n,
+                       void* stream);
 bool orb_quadtree_two_passes(const OrbGeom& g, int nframes);  // whether orb_launch_quadtree runs such a launch in two passes
 int orb_launch_fast(const OrbBatch& b);
 int orb_launch_quadtree(const OrbBatch& b);

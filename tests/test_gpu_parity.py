@@ -277,6 +277,44 @@ def test_extract_device_entry_point(hip, oracle):
     c.close()
 
 
+def test_extract_unaligned_rows(hip, oracle):
+    """Frames whose rows, first pixel or frame-to-frame distance are not multiples of four bytes (the library copies
+    them into aligned rows once; the stages read whole dwords): an odd width stored without padding, a view one
+    byte into a padded buffer, frames an odd number of bytes apart.  Every frame equals the oracle's."""
+    import torch
+
+    n, w, h = 3, 333, 251
+    c = hip.Context(500, 1.2, 6, 20, 7, w, h, n, 0, PRESETS["fork"])
+    e = oracle.Extractor(500, 1.2, 6, 20, 7, PRESETS["fork"])
+    imgs = np.stack([synth_scene(w, h, frame_seed(6, f)) for f in range(n)])
+    want = [e.extract(imgs[f]) for f in range(n)]
+    cap = c.cap
+    views = []
+    views.append(torch.from_numpy(imgs).cuda())                       # stride 333
+    buf = torch.zeros((n, h, 340), dtype=torch.uint8, device="cuda")   # aligned stride, first pixel at byte 1
+    buf[:, :, 1 : w + 1] = torch.from_numpy(imgs).cuda()
+    views.append(buf[:, :, 1 : w + 1])
+    flat = torch.zeros(n * (h * 336 + 3), dtype=torch.uint8, device="cuda")  # aligned rows, frames 84339 bytes apart
+    odd = torch.as_strided(flat, (n, h, w), (h * 336 + 3, 336, 1))
+    odd.copy_(torch.from_numpy(imgs).cuda())
+    views.append(odd)
+    for vi, d_imgs in enumerate(views):
+        d_kps = torch.zeros((n, cap, 28), dtype=torch.uint8, device="cuda")
+        d_desc = torch.zeros((n, cap, 32), dtype=torch.uint8, device="cuda")
+        d_cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+        c.extract_batch_device(d_imgs, d_kps, d_desc, d_cnt)
+        torch.cuda.synchronize()
+        c.check_last_batch()
+        cnt = d_cnt.cpu().numpy()
+        for f in range(n):
+            ko, do = want[f]
+            kg = d_kps[f, : cnt[f]].cpu().numpy().view(hip.KP_DTYPE).reshape(-1)
+            assert_kps_equal(kg, ko, "view %d frame %d" % (vi, f))
+            np.testing.assert_array_equal(d_desc[f, : cnt[f]].cpu().numpy(), do)
+    assert len(want[0][0]) > 100
+    c.close()
+
+
 def test_empty_and_invalid_inputs(hip):
     c = _ctx(hip, "fork")
     k, d = c.extract(np.zeros((0, 0), np.uint8))
