@@ -224,14 +224,21 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     uint8_t* bl = s_raw[wave];  // the blurred window (37 x 44 bytes) takes the place of the source window, which the
                                 // horizontal pass has consumed by the time the vertical pass writes it
 
-    // 43x43 source window.  Interior keypoints on 4-byte-aligned rows take whole dwords (12 per row,
-    // the window then starts `off` bytes into the LDS row); keypoints whose window leaves the level
-    // take bytes, reflected at the borders like the blur's BORDER_REFLECT_101.
+    // 43x43 source window.  On 4-byte-aligned rows it is fetched as whole dwords (12 per row, the window then starts
+    // `off` bytes into the LDS row): interior keypoints as they are; keypoints whose window leaves the level by its
+    // one or two rows or columns (a keypoint is at least 19 pixels from the edge, the window reaches 21) with the row
+    // numbers reflected like the blur's BORDER_REFLECT_101, dwords beyond the row fetched from its first or last
+    // dword instead, and the missing columns copied from their mirror images inside the window afterwards.  Rows
+    // off 4-byte boundaries take bytes.
     const int wx0 = px - 21, wy0 = py - 21;
     const int xa = wx0 & ~3;
-    const bool fastLoad = wx0 >= 0 && wy0 >= 0 && py + 21 < L.h && xa + 4 * RAW_DW <= L.w && (pitch & 3) == 0 &&
-                          (((unsigned long long)img) & 3ull) == 0;
-    const int off = fastLoad ? (wx0 - xa) : 0;
+    const bool dwordRows = (pitch & 3) == 0 && (((unsigned long long)img) & 3ull) == 0;
+    // (on the library's own levels the last dwords of a row may lie beyond the level's width, inside the row pitch:
+    // bytes that are no pixel of the window; the caller's level 0 is not read beyond its width)
+    const int rowLimit = level == 0 ? L.w : pitch;
+    const bool fastLoad = dwordRows && wx0 >= 0 && wy0 >= 0 && py + 21 < L.h && px + 21 < L.w && xa + 4 * RAW_DW <= rowLimit;
+    const bool borderLoad = dwordRows && !fastLoad && (rowLimit & 3) == 0 && rowLimit >= 4 * RAW_DW && L.h >= 4;
+    const int off = (fastLoad || borderLoad) ? (wx0 - xa) : 0;
     // the IC_Angle byte weights of this lane's five patch rows: requested now, used after the window is staged
     const int icRow = lane_div<9>(lane), icGroup = lane - icRow * 9;
     uint2 icm[5];
@@ -259,6 +266,31 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
 #pragma unroll
             for (int it = 0; it < 9; it++)
                 if (rr + 5 * it < RAW_N) dstw[it * 5 * (RAW_P / 4)] = v[it];
+        }
+    } else if (borderLoad) {
+        const int rr = lane_div<RAW_DW>(lane), d = lane - rr * RAW_DW;
+        if (rr < 5) {
+            const int colx = min(max(xa + 4 * d, 0), rowLimit - 4);
+            uint32_t* dstw = (uint32_t*)raw + rr * (RAW_P / 4) + d;
+            uint32_t v[9];
+#pragma unroll
+            for (int it = 0; it < 9; it++) {
+                const int y = wy0 + rr + 5 * it;
+                const int sy = y < 0 ? -y : (y >= L.h ? 2 * L.h - 2 - y : y);
+                if (rr + 5 * it < RAW_N) v[it] = *(const uint32_t*)(img + (int64_t)sy * pitch + colx);
+            }
+#pragma unroll
+            for (int it = 0; it < 9; it++)
+                if (rr + 5 * it < RAW_N) dstw[it * 5 * (RAW_P / 4)] = v[it];
+        }
+        const int nLeft = wx0 < 0 ? -wx0 : 0, nRight = wx0 + RAW_N > L.w ? wx0 + RAW_N - L.w : 0;  // at most 2 each
+        if (nLeft | nRight) {
+            wave_lds_sync();
+            if (lane < RAW_N) {
+                uint8_t* row = raw + lane * RAW_P + off;
+                for (int c = 0; c < nLeft; c++) row[c] = row[-2 * wx0 - c];                    // x = wx0 + c -> -x
+                for (int c = RAW_N - nRight; c < RAW_N; c++) row[c] = row[2 * (L.w - 1 - wx0) - c];  // x -> 2 (w - 1) - x
+            }
         }
     } else {
         for (int k = lane; k < RAW_N * RAW_N; k += 64) {
