@@ -23,7 +23,11 @@
 // so sharing the horizontal results between destination rows changes nothing.
 typedef float float2v __attribute__((ext_vector_type(2)));  // element-wise products and sums: v_pk_mul_f32 / v_pk_add_f32
 
-#define RS_TILES_PER_WG 2  // vertically adjacent tiles one workgroup makes in turn (PAIR instances)
+// Vertically adjacent tiles one workgroup makes in turn (PAIR instances): two, or four in launches over many frames
+// (fewer, longer workgroups: -3 % at 512 frames; at 8 and 64 frames four were 15 and 10 % slower than two).
+#define RS_TILES_PER_WG 2
+#define RS_TILES_PER_WG_MANY 4
+#define RS_MANY_FRAMES 256
 #define RS_STAGE_REGS 6  // dwords of a source tile one thread can hold while the previous tile is worked on
 
 // Everything about one workgroup's column of tiles that does not change from tile to tile.
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
                                                       int dpitch, int64_t dFrame, const void* __restrict__ xtab,
                                                       const void* __restrict__ ytab, uint64_t scaleX, uint64_t scaleY,
                                                       int tp, int rowsMax, int tilesX, int tilesY, int nframes,
-                                                      unsigned tilesXMagic, unsigned tilesMagic) {
+                                                      unsigned tilesXMagic, unsigned tilesMagic, int srcPadded, int tilesPerWg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
     const int t = threadIdx.x;
     RsTileCtx c;
@@ -173,9 +177,14 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
     const int rr = orb_div_small(t, nd), d = t - rr * nd;
     const int col = c.sxa + 4 * d;
     const bool stager = rr < rpp;
+    // A thread's dwords of all rows share their column: whether it can be fetched whole is settled once (on the
+    // library's own levels, srcPadded, also a dword that straddles the image width: the row pitch holds it, and the
+    // bytes beyond the width are no tap of any pixel), and a row's byte offset inside the frame fits 32 bits
+    // (checked by the launcher): one 24-bit multiply.
+    const bool dwordOk = aligned && (col + 3 < sw || (srcPadded && col + 4 <= sstride));
     auto fetch = [&](int sy0, int r) -> uint32_t {
-        const uint8_t* p = S + (int64_t)(sy0 + r) * sstride + col;
-        if (aligned && col + 3 < sw) return *(const uint32_t*)p;
+        const uint8_t* p = S + (__umul24((unsigned)(sy0 + r), (unsigned)sstride) + (unsigned)col);
+        if (dwordOk) return *(const uint32_t*)p;
         uint32_t v = 0u;
 #pragma unroll
         for (int i = 0; i < 4; i++)
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
         return;
     }
 
-    int y0 = by * (RS_TILES_PER_WG * ORB_RS_TH);
+    int y0 = by * (tilesPerWg * ORB_RS_TH);
     int sy0, nrows;
     rows_of(y0, &sy0, &nrows);
     uint32_t held[RS_STAGE_REGS];
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
         const int r = rr + k * rpp;
         held[k] = (stager && r < nrows) ? fetch(sy0, r) : 0u;
     }
-    for (int s = 0; s < RS_TILES_PER_WG; s++) {
+    for (int s = 0; s < tilesPerWg; s++) {
 #pragma unroll
         for (int k = 0; k < RS_STAGE_REGS; k++) {
             const int r = rr + k * rpp;
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
         __syncthreads();
         // the second tile's rows are requested now and awaited after the first tile is done
         const int ny0 = y0 + ORB_RS_TH;
-        const bool more = s + 1 < RS_TILES_PER_WG && ny0 < dh;
+        const bool more = s + 1 < tilesPerWg && ny0 < dh;
         int nsy0 = 0, nnrows = 0;
         if (more) {
             rows_of(ny0, &nsy0, &nnrows);
@@ -320,7 +329,11 @@ static int check_launch(const char* what) {
 
 static int launch_resize(bool area, int ntaps, const uint8_t* src, int sw, int sh, int sstride, int64_t sFrame, uint8_t* dst, int dw,
                          int dh, int dpitch, int64_t dFrame, const void* xt, const void* yt, int nframes,
-                         hipStream_t st) {
+                         hipStream_t st, bool srcPadded) {
+    if ((int64_t)sh * sstride > 0x7fffffffll || sh >= (1 << 24) || sstride >= (1 << 24)) {
+        orb_set_error("resize: a source frame of %d rows of %d bytes is beyond the kernel's 32-bit row offsets", sh, sstride);
+        return ORB_ERR_UNSUPPORTED;
+    }
     const uint64_t scaleX = orb_resize_scale_fx(sw, dw), scaleY = orb_resize_scale_fx(sh, dh);
     int tp = 0, rows = 0;
     orb_resize_tile_extent(sw, dw, scaleX, ORB_RS_TW, true, &tp);
@@ -337,13 +350,14 @@ static int launch_resize(bool area, int ntaps, const uint8_t* src, int sw, int s
     const int rowsPerPass = 256 / (tp / 4);
     const bool pair = (rows + rowsPerPass - 1) / rowsPerPass <= RS_STAGE_REGS && tilesY > 1;
     const int tilesX = (dw + ORB_RS_TW - 1) / ORB_RS_TW;
-    const int tilesYwg = pair ? (tilesY + RS_TILES_PER_WG - 1) / RS_TILES_PER_WG : tilesY;
+    const int tilesPerWg = !pair ? 1 : nframes >= RS_MANY_FRAMES ? RS_TILES_PER_WG_MANY : RS_TILES_PER_WG;
+    const int tilesYwg = (tilesY + tilesPerWg - 1) / tilesPerWg;
     const dim3 grid((unsigned)orb_xcd_grid(nframes, (int64_t)tilesX * tilesYwg));
 #define RS_LAUNCH(AREA_, NT_, PAIR_)                                                                                  \
     hipLaunchKernelGGL((k_resize_tiled<AREA_, NT_, PAIR_>), grid, dim3(256), lds, st, src, sw, sh, sstride, sFrame, dst, \
                        dw, dh, dpitch, dFrame, xt, yt, scaleX, scaleY, tp, rows, tilesX, tilesYwg, nframes,       \
                        orb_div_magic((uint32_t)tilesX, (uint64_t)tilesX * tilesYwg),                               \
-                       orb_div_magic((uint32_t)(tilesX * tilesYwg), (uint64_t)grid.x))
+                       orb_div_magic((uint32_t)(tilesX * tilesYwg), (uint64_t)grid.x), srcPadded ? 1 : 0, tilesPerWg)
     if (area && ntaps <= 3) {
         if (pair) RS_LAUNCH(true, 3, true); else RS_LAUNCH(true, 3, false);
     } else if (area) {
@@ -500,7 +514,7 @@ int orb_launch_pyramid(const OrbBatch& b) {
         const void* yt = area ? (const void*)(b.d_areaTaps + D.tabY) : (const void*)(b.d_linTaps + D.tabY);
         int rc = launch_resize(area, g.areaTapsMax, src + b.frame0 * sFrame, P.w, P.h, sstride, sFrame,
                                b.d_pyr + D.off + b.frame0 * D.frameStride, D.w, D.h, D.pitch, D.frameStride, xt, yt,
-                               b.nframes, st);
+                               b.nframes, st, l > 1);  // (levels >= 1 lie in the library's padded rows)
         if (rc) return rc;
     }
     return ORB_OK;
@@ -511,7 +525,7 @@ int orb_launch_resize_single(const uint8_t* d_src, int sw, int sh, int sstride, 
                              const OrbLinTap* d_ly, int area, void* stream) {
     return launch_resize(area != 0, ORB_MAX_TAPS, d_src, sw, sh, sstride, 0, d_dst, dw, dh, dstride, 0,
                          area ? (const void*)d_ax : (const void*)d_lx, area ? (const void*)d_ay : (const void*)d_ly, 1,
-                         (hipStream_t)stream);
+                         (hipStream_t)stream, false);
 }
 
 int orb_launch_blur_single(const uint8_t* d_src, int w, int h, int sstride, uint8_t* d_dst, int dstride, int legacy,
