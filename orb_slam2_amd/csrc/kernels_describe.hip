@@ -27,6 +27,7 @@
 #define HB_P 40    // horizontal sums (16 bit) of a row pair per column of those groups: one dword each
 #endif
 #define HB_PAIRS 22  // row pairs (0,1) .. (42,43); row 43 does not exist, its sums meet weight 0 only
+#define HB_SLOTS 18  // row pairs whose sums are held in LDS at a time (the passes work on half the window in turn)
 #define BL_N 37
 #ifndef BL_P
 #define BL_P 44
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
                                                              int capPerFrame, int* __restrict__ nOut,
                                                              int* __restrict__ error, int* __restrict__ status) {
     __shared__ __attribute__((aligned(16))) uint8_t s_raw[DESC_WAVES][(RAW_N + 1) * RAW_P];  // + the partner row of row 42
-    __shared__ __attribute__((aligned(16))) uint32_t s_hb[DESC_WAVES][HB_PAIRS * HB_P];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hb[DESC_WAVES][HB_SLOTS * HB_P];
     // the wavefront index is the same in all 64 lanes: telling the compiler so keeps everything derived from
     // it (frame, level, keypoint, window addresses, loop bounds) in scalar registers
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -348,69 +349,88 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     // takes its seven rows as four such dwords whatever the parity of its first row, with no shuffling.
     const int rr = lane_div<HGROUPS>(lane), qi = lane - rr * HGROUPS;
     const int q = ((off + 3) >> 2) + qi;  // the group's place in the LDS rows of the source and blurred windows
-    if (rr < HROWS) {
-        const int back = q > 0 ? -1 : 0;
+    // The two passes take turns, half of the window each, so that the sums of only 13 row pairs have to be held at a
+    // time (HB_SLOTS slots of LDS instead of 22: 5.0 KB per wavefront, 32 wavefronts per CU instead of 29):
+    //   A  horizontal sums of row pairs 0..11 -> slots pair + 6, pairs 9..11 also -> slots 0..2
+    //   B  blurred rows 0..17 (they need pairs 0..11), written over source rows 0..16, which A has consumed
+    //   C  horizontal sums of row pairs 12..21 -> slots pair - 9 = 3..12 (over the sums B has consumed)
+    //   D  blurred rows 18..36 (pairs 9..21 = slots 0..12), written over the source rows C has consumed
+    // LDS operations of the one wavefront execute in program order; the syncs only keep the compiler from moving
+    // them across.
+    const int back = q > 0 ? -1 : 0;
+    auto hpass = [&](int pr, int slot, bool alsoLow) {
+        const uint32_t* p = raw32 + 2 * pr * (RAW_P / 4) + q;
+        uint32_t o[2][4];
 #pragma unroll
-        for (int it = 0; it < (HB_PAIRS + HROWS - 1) / HROWS; it++) {
-            const int pr = rr + HROWS * it;
-            if (pr < HB_PAIRS) {
-                const uint32_t* p = raw32 + 2 * pr * (RAW_P / 4) + q;
-                uint32_t o[2][4];
-#pragma unroll
-                for (int h = 0; h < 2; h++, p += RAW_P / 4) {
-                    const uint32_t A = p[back], B = p[0], C = p[1];
-                    // output m of the group sums bytes m-3 .. m+3 around column 4q + m: the seven taps laid over
-                    // the three aligned dwords that hold them (no byte alignment of the data)
-                    o[h][0] = dot4_u8(A, wA0, dot4_u8(B, wB0, 0u));
-                    o[h][1] = dot4_u8(A, wA1, dot4_u8(B, wB1, dot4_u8(C, wC1, 0u)));
-                    o[h][2] = dot4_u8(A, wA2, dot4_u8(B, wB2, dot4_u8(C, wC2, 0u)));
-                    o[h][3] = dot4_u8(B, wB3, dot4_u8(C, wC3, 0u));
-                }
-                uint4 e;  // (sums stay below 2^16)
-                e.x = (o[1][0] << 16) + o[0][0];
-                e.y = (o[1][1] << 16) + o[0][1];
-                e.z = (o[1][2] << 16) + o[0][2];
-                e.w = (o[1][3] << 16) + o[0][3];
-                *(uint4*)(hb32 + pr * HB_P + 4 * qi) = e;
-            }
+        for (int h = 0; h < 2; h++, p += RAW_P / 4) {
+            const uint32_t A = p[back], B = p[0], C = p[1];
+            // output m of the group sums bytes m-3 .. m+3 around column 4q + m: the seven taps laid over
+            // the three aligned dwords that hold them (no byte alignment of the data)
+            o[h][0] = dot4_u8(A, wA0, dot4_u8(B, wB0, 0u));
+            o[h][1] = dot4_u8(A, wA1, dot4_u8(B, wB1, dot4_u8(C, wC1, 0u)));
+            o[h][2] = dot4_u8(A, wA2, dot4_u8(B, wB2, dot4_u8(C, wC2, 0u)));
+            o[h][3] = dot4_u8(B, wB3, dot4_u8(C, wC3, 0u));
         }
-    }
-    wave_lds_sync();
+        uint4 e;  // (sums stay below 2^16)
+        e.x = (o[1][0] << 16) + o[0][0];
+        e.y = (o[1][1] << 16) + o[0][1];
+        e.z = (o[1][2] << 16) + o[0][2];
+        e.w = (o[1][3] << 16) + o[0][3];
+        *(uint4*)(hb32 + slot * HB_P + 4 * qi) = e;
+        if (alsoLow && pr >= 9) *(uint4*)(hb32 + (pr - 9) * HB_P + 4 * qi) = e;
+    };
     uint32_t* bl32 = (uint32_t*)bl;
     // tap pairs against (row 2p, row 2p + 1) for an even first row r = 2p, and for an odd one r = 2p + 1
     const uint32_t wE0 = k0 | (k1 << 16), wE1 = k2 | (k3 << 16), wE2 = k2 | (k1 << 16), wE3 = k0;
     const uint32_t wO0 = k0 << 16, wO1 = k1 | (k2 << 16), wO2 = k3 | (k2 << 16), wO3 = k1 | (k0 << 16);
-    if (rr < HROWS) {
-        // HROWS is even: all rows of a lane have the parity of its first one
-        static_assert(HROWS % 2 == 0, "the tap words are chosen once per lane");
-        const bool odd = (rr & 1) != 0;
-        const uint32_t w0 = odd ? wO0 : wE0, w1 = odd ? wO1 : wE1, w2 = odd ? wO2 : wE2, w3 = odd ? wO3 : wE3;
-#pragma unroll 1
-        for (int r = rr; r < BL_N; r += HROWS) {
-            const uint32_t* p = hb32 + __umul24((unsigned)(r >> 1), HB_P) + 4 * qi;
-            const uint4 e0 = *(const uint4*)p, e1 = *(const uint4*)(p + HB_P), e2 = *(const uint4*)(p + 2 * HB_P),
-                        e3 = *(const uint4*)(p + 3 * HB_P);
-            const uint32_t c0[4] = {e0.x, e0.y, e0.z, e0.w}, c1[4] = {e1.x, e1.y, e1.z, e1.w};
-            const uint32_t c2[4] = {e2.x, e2.y, e2.z, e2.w}, c3[4] = {e3.x, e3.y, e3.z, e3.w};
-            uint32_t v[4];
+    // HROWS is even: all rows of a lane have the parity of its first one
+    static_assert(HROWS % 2 == 0, "the tap words are chosen once per lane");
+    const bool odd = (rr & 1) != 0;
+    const uint32_t w0 = odd ? wO0 : wE0, w1 = odd ? wO1 : wE1, w2 = odd ? wO2 : wE2, w3 = odd ? wO3 : wE3;
+    auto vpass = [&](int r, int slot) {  // blurred row r from the four slots that hold rows r .. r + 7
+        const uint32_t* p = hb32 + __umul24((unsigned)slot, HB_P) + 4 * qi;
+        const uint4 e0 = *(const uint4*)p, e1 = *(const uint4*)(p + HB_P), e2 = *(const uint4*)(p + 2 * HB_P),
+                    e3 = *(const uint4*)(p + 3 * HB_P);
+        const uint32_t c0[4] = {e0.x, e0.y, e0.z, e0.w}, c1[4] = {e1.x, e1.y, e1.z, e1.w};
+        const uint32_t c2[4] = {e2.x, e2.y, e2.z, e2.w}, c3[4] = {e3.x, e3.y, e3.z, e3.w};
+        uint32_t v[4];
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                v[c] = dot2_u16(c0[c], w0, 32768u);
-                v[c] = dot2_u16(c1[c], w1, v[c]);
-                v[c] = dot2_u16(c2[c], w2, v[c]);
-                v[c] = dot2_u16(c3[c], w3, v[c]);
-            }
-            uint32_t packed;
-            if (legacy) {  // these taps sum to 257: the rounded value can pass 255
-                packed = 0;
-#pragma unroll
-                for (int c = 0; c < 4; c++) packed |= min(v[c] >> 16, 255u) << (8 * c);
-            } else {       // taps summing to 256 cannot: (255 * 256 * 256 + 2^15) >> 16 == 255; the pixel is byte 2
-                packed = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u),
-                                               __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), 0x05040100u);
-            }
-            bl32[r * (BL_P / 4) + q] = packed;
+        for (int c = 0; c < 4; c++) {
+            v[c] = dot2_u16(c0[c], w0, 32768u);
+            v[c] = dot2_u16(c1[c], w1, v[c]);
+            v[c] = dot2_u16(c2[c], w2, v[c]);
+            v[c] = dot2_u16(c3[c], w3, v[c]);
         }
+        uint32_t packed;
+        if (legacy) {  // these taps sum to 257: the rounded value can pass 255
+            packed = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) packed |= min(v[c] >> 16, 255u) << (8 * c);
+        } else {       // taps summing to 256 cannot: (255 * 256 * 256 + 2^15) >> 16 == 255; the pixel is byte 2
+            packed = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u),
+                                           __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), 0x05040100u);
+        }
+        bl32[r * (BL_P / 4) + q] = packed;
+    };
+    static_assert(HROWS == 6 && HB_PAIRS == 22 && BL_N == 37 && HB_SLOTS >= 18, "the phases below are laid out for these");
+    if (rr < HROWS) {
+        hpass(rr, rr + 6, false);           // A: pairs 0..5
+        hpass(rr + 6, rr + 12, true);       //    pairs 6..11
+    }
+    wave_lds_sync();
+    if (rr < HROWS) {
+#pragma unroll 1
+        for (int r = rr; r < 18; r += HROWS) vpass(r, (r >> 1) + 6);  // B
+    }
+    wave_lds_sync();
+    if (rr < HROWS) {
+        hpass(rr + 12, rr + 3, false);      // C: pairs 12..17
+        if (rr + 18 < HB_PAIRS) hpass(rr + 18, rr + 9, false);  // pairs 18..21
+    }
+    wave_lds_sync();
+    if (rr < HROWS) {
+#pragma unroll 1
+        for (int r = rr + 18; r < BL_N; r += HROWS) vpass(r, (r >> 1) - 9);  // D
     }
     wave_lds_sync();
     bl += off + 3;  // blurred window pixel (r, c), c = 0..36, is bl[r * BL_P + c] from here on
