@@ -302,20 +302,30 @@ __global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ src, 
 
 // Frames whose rows do not start on 4-byte boundaries (a 1241-pixel-wide frame stored without padding) would send
 // every kernel that stages level 0 down its byte-by-byte path; they are copied once into rows of an aligned
-// pitch instead.  Thread = four destination bytes of one row.
+// pitch instead.  Thread = sixteen destination bytes of one row, made from the five aligned source dwords that hold
+// them (v_alignbyte_b32); a source dword is only read when one of its bytes is a pixel of the row, so no read
+// leaves the pages the frames lie in.
 __global__ __launch_bounds__(256) void k_realign_rows(const uint8_t* __restrict__ src, int w, int sstride, int64_t sFrame,
                                                       uint8_t* __restrict__ dst, int dpitch, int64_t dFrame, int rowsPerFrame,
-                                                      int blocksPerRow) {
-    const int row = blockIdx.x / blocksPerRow;  // over all frames
-    const int x = 4 * ((blockIdx.x - row * blocksPerRow) * 256 + threadIdx.x);
-    if (x >= w) return;
+                                                      unsigned perRow, long long total) {
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= total) return;
+    const int row = (int)(id / perRow);  // over all frames
+    const int x = 16 * (int)(id - (long long)row * perRow);
     const int frame = row / rowsPerFrame, y = row - frame * rowsPerFrame;
-    const uint8_t* p = src + frame * sFrame + (int64_t)y * sstride + x;
-    uint32_t v = 0u;
+    const uint8_t* rowp = src + frame * sFrame + (int64_t)y * sstride;
+    const unsigned long long first = (unsigned long long)(rowp + x), last = (unsigned long long)(rowp + w - 1);
+    const uint32_t* a0 = (const uint32_t*)(first & ~3ull);
+    const unsigned sh = (unsigned)(first & 3ull);
+    uint32_t d[5];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-        if (x + i < w) v |= (uint32_t)p[i] << (8 * i);
-    *(uint32_t*)(dst + frame * dFrame + (int64_t)y * dpitch + x) = v;
+    for (int k = 0; k < 5; k++) d[k] = ((unsigned long long)(a0 + k) <= last && (k < 4 || sh)) ? a0[k] : 0u;
+    uint4 o;
+    o.x = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
+    o.y = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
+    o.z = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
+    o.w = __builtin_amdgcn_alignbyte(d[4], d[3], sh);
+    *(uint4*)(dst + frame * dFrame + (int64_t)y * dpitch + x) = o;  // (x + 16 <= dpitch: the pitch is a multiple of 64)
 }
 
 static int check_launch(const char* what) {
@@ -493,9 +503,10 @@ static int launch_pyramid_few(const OrbBatch& b) {
 int orb_launch_realign(const uint8_t* src, int w, int h, int sstride, int64_t sFrame, uint8_t* dst, int dpitch, int n,
                        void* stream) {
     // (dpitch is a multiple of 64 and at least w: the last dword of a row lies inside it)
-    const int blocksPerRow = (w + 1023) / 1024;
-    hipLaunchKernelGGL(k_realign_rows, dim3((unsigned)((int64_t)n * h * blocksPerRow)), dim3(256), 0, (hipStream_t)stream, src, w,
-                       sstride, sFrame, dst, dpitch, (int64_t)dpitch * h, h, blocksPerRow);
+    const unsigned perRow = (unsigned)((w + 15) / 16);
+    const long long total = (long long)n * h * perRow;
+    hipLaunchKernelGGL(k_realign_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, w, sstride, sFrame,
+                       dst, dpitch, (int64_t)dpitch * h, h, perRow, total);
     return check_launch("row realignment");
 }
 

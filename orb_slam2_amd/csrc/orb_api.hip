@@ -771,7 +771,7 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
     // rows that do not start on 4-byte boundaries: one copy into the context's aligned input block (sized at
     // orb_create for the largest batch), which every stage then reads with whole dwords
     if (((unsigned long long)d_img0 | (unsigned long long)stride | (unsigned long long)frameStride) & 3ull) {
-        if ((int64_t)n * h * ((w + 1023) / 1024) > 0x7fffffff) {
+        if ((int64_t)n * h * ((w + 15) / 16) > 0x7fffffffll * 128) {
             orb_set_error("batch too large for the row realignment");
             return ORB_ERR_UNSUPPORTED;
         }
