@@ -2,6 +2,9 @@
 // management and the extraction entry points of include/orb_hip.h.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -86,7 +89,9 @@ struct PinBuf {  // page-locked host staging: one DMA per direction instead of p
 
 #define ORB_MAX_PARTS 4
 #define ORB_STAGE_THREADS 16     // most host threads that stage a batch of host frames (orb_ctx::stageThreads are used)
-#define ORB_STAGE_SLICE 4        // frames per host-to-device copy
+#define ORB_STAGE_SLICE 4        // batches below this many frames are staged and copied in one piece
+#define ORB_STAGE_SLICE_BYTES (5 << 19)  // bytes per host-to-device copy of a larger batch, about
+#define ORB_MAX_STAGE_SLICES 64
 #define ORB_MIN_PART_FRAMES 8   // groups smaller than this do not fill the device; the batch is then not split
 
 struct orb_ctx {
@@ -106,6 +111,7 @@ struct orb_ctx {
     // levels) run under the throughput-bound stages of another.
     hipStream_t aux[ORB_MAX_PARTS - 1] = {};
     hipEvent_t evFork = nullptr, evJoin[ORB_MAX_PARTS - 1] = {};
+    hipEvent_t evIn = nullptr;  // host-pointer batches: the frames of every group but the first have arrived
     int parts = 2;
     int stageThreads = 4;
     DevBuf dGeom, dAreaTaps, dLinTaps, dCodeTab, dInput, dPyr, dCellKeys, dCellCount, dSort, dNodes, dInts,
@@ -668,6 +674,7 @@ extern "C" int orb_create(const orb_params* prm, orb_ctx** out) {
         CREATE_TRY(hipEventCreateWithFlags(&c->evJoin[i], hipEventDisableTiming));
     }
     CREATE_TRY(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&c->evIn, hipEventDisableTiming));
 #undef CREATE_TRY
     // size everything for the largest announced frame and batch now, so steady-state calls allocate nothing
     int rc = compute_geom(c, prm->max_width, prm->max_height);
@@ -703,6 +710,7 @@ extern "C" void orb_destroy(orb_ctx* c) {
         if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
     }
     if (c->evFork) (void)hipEventDestroy(c->evFork);
+    if (c->evIn) (void)hipEventDestroy(c->evIn);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -745,9 +753,15 @@ extern "C" int orb_compute_tables(const orb_params* prm, float* scale, float* in
     return orb_get_tables(&tmp, scale, inv_scale, sigma2, inv_sigma2, per_level, umax);
 }
 
-// Enqueue the whole extraction for n frames whose level 0 is at d_img0.
+// Frame groups a batch of n frames is enqueued as (group i = frames [n i / parts, n (i + 1) / parts)).
+static int batch_parts(const orb_ctx* c, int n) { return c->timing ? 1 : std::max(1, std::min(c->parts, n / ORB_MIN_PART_FRAMES)); }
+
+// Enqueue the whole extraction for n frames whose level 0 is at d_img0.  laterGroupsInput, when given, is an event
+// after which the frames of every group but the first are in place (the first group's are by the time the stream
+// reaches its kernels): those groups then wait for it instead of for the stream's earlier work.
 static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int stride, int64_t frameStride,
-                     orb_keypoint* d_kps, uint8_t* d_desc, int cap, int* d_nOut, hipStream_t st, int* d_status = nullptr) {
+                     orb_keypoint* d_kps, uint8_t* d_desc, int cap, int* d_nOut, hipStream_t st, int* d_status = nullptr,
+                     hipEvent_t laterGroupsInput = nullptr) {
     if (n < 1 || n > c->prm.max_batch) {
         orb_set_error("batch of %d frames outside 1..max_batch=%d", n, c->prm.max_batch);
         return ORB_ERR_INVALID;
@@ -826,8 +840,8 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
         HIP_TRY(hipEventRecord(ev[4], st));
         return ORB_OK;
     }
-    const int parts = std::max(1, std::min(c->parts, n / ORB_MIN_PART_FRAMES));
-    if (parts > 1) HIP_TRY(hipEventRecord(c->evFork, st));
+    const int parts = batch_parts(c, n);
+    if (parts > 1 && !laterGroupsInput) HIP_TRY(hipEventRecord(c->evFork, st));
     // stage by stage across the groups, so that the queues hold comparable work at any time
     OrbBatch pb[ORB_MAX_PARTS];
     for (int i = 0; i < parts; i++) {
@@ -836,7 +850,7 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
         pb[i].nframes = (int)((int64_t)n * (i + 1) / parts) - pb[i].frame0;
         if (i > 0) {
             pb[i].stream = c->aux[i - 1];
-            HIP_TRY(hipStreamWaitEvent(c->aux[i - 1], c->evFork, 0));
+            HIP_TRY(hipStreamWaitEvent(c->aux[i - 1], laterGroupsInput ? laterGroupsInput : c->evFork, 0));
         }
     }
     c->lastGroups = 0;
@@ -978,19 +992,21 @@ extern "C" int orb_extract_batch(orb_ctx* c, const uint8_t* const* imgs, int n, 
     const int cap = orb_max_keypoints_per_frame(c);
     const int dstride = c->inputStride;
     const int64_t fstride = (int64_t)dstride * h;
-    // frames -> page-locked staging in the device layout (row copies on the host) -> device.  A single
-    // host thread copies at a fraction of the link rate, so a batch is staged by up to four threads, each
-    // handing its frames to the DMA engine in slices as it goes (host copies and DMA overlap).
+    // frames -> page-locked staging in the device layout (row copies on the host) -> device.  A single host thread
+    // copies at a fraction of the link rate, so a batch is staged by up to four threads, slice by slice, and every
+    // slice is handed to the DMA engine as soon as it is staged (host copies and DMA overlap).  The copies go to ONE
+    // stream, in a fixed order (copies on several streams at once share the link badly: 17 instead of 56 GB/s), in
+    // slices of about 2.5 MB (a copy costs some 10 us beyond its bytes: 1.2 MB slices ran at 35 GB/s).  The frames of
+    // the later frame groups go first and an event marks their arrival: those groups start extracting while the first
+    // group's frames, the last to arrive, are still on the link.
     if ((rc = c->pinIn.ensure((size_t)n * fstride))) return rc;
     for (int f = 0; f < n; f++)
         if (!imgs[f]) {
             orb_set_error("frame %d is null", f);
             return ORB_ERR_INVALID;
         }
-    const bool few = n < ORB_STAGE_SLICE;
-    if (few) {
-        // a few frames (the reference's one-frame-per-call use): one host thread, one copy
-        for (int f = 0; f < n; f++) {
+    auto stage_frames = [&](int f0, int f1) {
+        for (int f = f0; f < f1; f++) {
             uint8_t* dst = (uint8_t*)c->pinIn.p + f * fstride;
             if (stride == dstride) {
                 memcpy(dst, imgs[f], (size_t)stride * (h - 1) + w);
@@ -998,25 +1014,39 @@ extern "C" int orb_extract_batch(orb_ctx* c, const uint8_t* const* imgs, int n, 
                 for (int r = 0; r < h; r++) memcpy(dst + (size_t)r * dstride, imgs[f] + (size_t)r * stride, (size_t)w);
             }
         }
+    };
+    const bool few = n < ORB_STAGE_SLICE;
+    static const bool trace = getenv("ORBHIP_HOST_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double T0 = now();
+    double T1 = 0, T2 = 0, T3 = 0;
+    hipEvent_t laterIn = nullptr;
+    if (few) {
+        // a few frames (the reference's one-frame-per-call use): one host thread, one copy
+        stage_frames(0, n);
         HIP_TRY(hipMemcpyAsync(c->dInput.p, c->pinIn.p, (size_t)n * fstride, hipMemcpyHostToDevice, c->stream));
     } else {
-        const int nthreads = std::max(1, std::min(c->stageThreads, n / ORB_STAGE_SLICE));
+        const int parts = batch_parts(c, n);
+        const int g1 = parts > 1 ? n / parts : 0;  // frames [g1, n) belong to the later groups
+        const int per = (int)std::max<int64_t>(1, std::min<int64_t>(n, ORB_STAGE_SLICE_BYTES / fstride));
+        int sl0[ORB_MAX_STAGE_SLICES], sl1[ORB_MAX_STAGE_SLICES], nsl = 0, nLater = 0;
+        const int perCapped = std::max(per, (n + ORB_MAX_STAGE_SLICES - 2) / (ORB_MAX_STAGE_SLICES - 1));
+        for (int s0 = g1; s0 < n; s0 += perCapped) sl0[nsl] = s0, sl1[nsl++] = std::min(n, s0 + perCapped);
+        nLater = g1 > 0 ? nsl : 0;
+        for (int s0 = 0; s0 < g1; s0 += perCapped) sl0[nsl] = s0, sl1[nsl++] = std::min(g1, s0 + perCapped);
+        const int nthreads = std::max(1, std::min(c->stageThreads, nsl));
         hipError_t terr[ORB_STAGE_THREADS];
+        std::atomic<int> ticket{0};  // the slice whose copy is enqueued next
         auto stage = [&](int t) {
             terr[t] = t ? hipSetDevice(c->prm.device) : hipSuccess;
-            const int f0 = (int)((int64_t)n * t / nthreads), f1 = (int)((int64_t)n * (t + 1) / nthreads);
-            for (int s0 = f0; s0 < f1 && terr[t] == hipSuccess; s0 += ORB_STAGE_SLICE) {
-                const int s1 = std::min(f1, s0 + ORB_STAGE_SLICE);
-                for (int f = s0; f < s1; f++) {
-                    uint8_t* dst = (uint8_t*)c->pinIn.p + f * fstride;
-                    if (stride == dstride) {
-                        memcpy(dst, imgs[f], (size_t)stride * (h - 1) + w);
-                    } else {
-                        for (int r = 0; r < h; r++) memcpy(dst + (size_t)r * dstride, imgs[f] + (size_t)r * stride, (size_t)w);
-                    }
-                }
-                terr[t] = hipMemcpyAsync((uint8_t*)c->dInput.p + s0 * fstride, (uint8_t*)c->pinIn.p + s0 * fstride,
-                                         (size_t)(s1 - s0) * fstride, hipMemcpyHostToDevice, c->stream);
+            for (int k = t; k < nsl; k += nthreads) {
+                if (terr[t] == hipSuccess) stage_frames(sl0[k], sl1[k]);
+                while (ticket.load(std::memory_order_acquire) != k) std::this_thread::yield();
+                if (terr[t] == hipSuccess)
+                    terr[t] = hipMemcpyAsync((uint8_t*)c->dInput.p + sl0[k] * fstride, (uint8_t*)c->pinIn.p + sl0[k] * fstride,
+                                             (size_t)(sl1[k] - sl0[k]) * fstride, hipMemcpyHostToDevice, c->stream);
+                if (terr[t] == hipSuccess && k + 1 == nLater) terr[t] = hipEventRecord(c->evIn, c->stream);
+                ticket.store(k + 1, std::memory_order_release);  // (also after a failure: the others must not wait for ever)
             }
         };
         std::thread workers[ORB_STAGE_THREADS];
@@ -1024,11 +1054,13 @@ extern "C" int orb_extract_batch(orb_ctx* c, const uint8_t* const* imgs, int n, 
         stage(0);
         for (int t = 1; t < nthreads; t++) workers[t].join();
         for (int t = 0; t < nthreads; t++) HIP_TRY(terr[t]);
+        if (nLater > 0) laterIn = c->evIn;
     }
     // results: [flag words | counts | keypoints (cap per frame) | descriptors] as one block.  A batch leaves it in
     // device memory and fetches it with one copy; a few frames write it straight into the page-locked host block
     // (the last kernel stores the rows over the link itself: a copy between two kernels and the synchronisation
     // costs more than the 64 KB per frame take), with the flag word as the last stage saw it per frame.
+    T1 = now();
     const size_t offCnt = 64, offKps = offCnt + (((size_t)n * 4 + 63) & ~(size_t)63);
     const size_t offDesc = offKps + (size_t)n * cap * sizeof(orb_keypoint);
     const size_t total = offDesc + (size_t)n * cap * 32;
@@ -1046,11 +1078,13 @@ extern "C" int orb_extract_batch(orb_ctx* c, const uint8_t* const* imgs, int n, 
     } else {
         uint8_t* dOut = (uint8_t*)c->dHostOut.p;
         rc = run_batch(c, (const uint8_t*)c->dInput.p, n, w, h, dstride, fstride, (orb_keypoint*)(dOut + offKps), dOut + offDesc,
-                       cap, (int*)(dOut + offCnt), c->stream);
+                       cap, (int*)(dOut + offCnt), c->stream, nullptr, laterIn);
         if (rc) return rc;
+        T2 = now();
         HIP_TRY(hipMemcpyAsync(po, dOut, (kps || desc) ? (desc ? total : offDesc) : offKps, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    T3 = now();
     if (*(const int*)po != 0) return read_error_flag(c);
     memcpy(n_out, po + offCnt, (size_t)n * 4);
     for (int f = 0; f < n; f++) {
@@ -1066,6 +1100,7 @@ extern "C" int orb_extract_batch(orb_ctx* c, const uint8_t* const* imgs, int n, 
             if (desc) memcpy(desc + (size_t)f * cap_per_frame * 32, po + offDesc + (size_t)f * cap * 32, (size_t)m * 32);
         }
     }
+    if (trace) fprintf(stderr, "host batch %d: stage+enqueue %.0f us, launch %.0f us, wait %.0f us, unpack %.0f us (result block %zu bytes)\n", n, T1 - T0, T2 - T1, T3 - T2, now() - T3, total);
     return ORB_OK;
 }
 
