@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--bf-steps", type=int, default=3)
     ap.add_argument("--no-hamming", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=100)
+    ap.add_argument("--cpu-frames", type=int, default=300, help="frames the single-thread CPU baseline extracts (about 10 s)")
     ap.add_argument("--no-extras", action="store_true", help="skip batch sweep, host path, single frame and other configurations")
     args = ap.parse_args()
 

@@ -90,7 +90,7 @@ struct PinBuf {  // page-locked host staging: one DMA per direction instead of p
 #define ORB_MAX_PARTS 4
 #define ORB_STAGE_THREADS 16     // most host threads that stage a batch of host frames (orb_ctx::stageThreads are used)
 #define ORB_STAGE_SLICE 4        // batches below this many frames are staged and copied in one piece
-#define ORB_STAGE_SLICE_BYTES (5 << 19)  // bytes per host-to-device copy of a larger batch, about
+#define ORB_STAGE_SLICE_BYTES (5 << 20)  // bytes per host-to-device copy of a larger batch, about
 #define ORB_MAX_STAGE_SLICES 64
 #define ORB_MIN_PART_FRAMES 8   // groups smaller than this do not fill the device; the batch is then not split
 
@@ -996,7 +996,9 @@ extern "C" int orb_extract_batch(orb_ctx* c, const uint8_t* const* imgs, int n, 
     // copies at a fraction of the link rate, so a batch is staged by up to four threads, slice by slice, and every
     // slice is handed to the DMA engine as soon as it is staged (host copies and DMA overlap).  The copies go to ONE
     // stream, in a fixed order (copies on several streams at once share the link badly: 17 instead of 56 GB/s), in
-    // slices of about 2.5 MB (a copy costs some 10 us beyond its bytes: 1.2 MB slices ran at 35 GB/s).  The frames of
+    // slices of about 5 MB (consecutive copies on a stream leave 18 us between them and cost the enqueuing thread
+    // 15 us each: 1.2 MB slices ran at 35 GB/s; a kernel that reads the staging block over the link itself has no
+    // such gaps but is slower, 0.89 against 0.82 ms for 64 frames).  The frames of
     // the later frame groups go first and an event marks their arrival: those groups start extracting while the first
     // group's frames, the last to arrive, are still on the link.
     if ((rc = c->pinIn.ensure((size_t)n * fstride))) return rc;
@@ -1034,19 +1036,24 @@ extern "C" int orb_extract_batch(orb_ctx* c, const uint8_t* const* imgs, int n, 
         for (int s0 = g1; s0 < n; s0 += perCapped) sl0[nsl] = s0, sl1[nsl++] = std::min(n, s0 + perCapped);
         nLater = g1 > 0 ? nsl : 0;
         for (int s0 = 0; s0 < g1; s0 += perCapped) sl0[nsl] = s0, sl1[nsl++] = std::min(g1, s0 + perCapped);
-        const int nthreads = std::max(1, std::min(c->stageThreads, nsl));
+        // every slice is staged by all the threads together, a share of its frames each; whoever finishes a slice's
+        // last share hands the slice to the DMA engine.  A thread takes the slices in order, so the last share of
+        // slice k is finished after its owner has enqueued every earlier slice it completed: copies are enqueued
+        // in slice order without any waiting.
+        const int nthreads = std::max(1, std::min(c->stageThreads, n / ORB_STAGE_SLICE));
         hipError_t terr[ORB_STAGE_THREADS];
-        std::atomic<int> ticket{0};  // the slice whose copy is enqueued next
+        std::atomic<int> arrived[ORB_MAX_STAGE_SLICES];
+        for (int k = 0; k < nsl; k++) arrived[k].store(0, std::memory_order_relaxed);
         auto stage = [&](int t) {
             terr[t] = t ? hipSetDevice(c->prm.device) : hipSuccess;
-            for (int k = t; k < nsl; k += nthreads) {
-                if (terr[t] == hipSuccess) stage_frames(sl0[k], sl1[k]);
-                while (ticket.load(std::memory_order_acquire) != k) std::this_thread::yield();
-                if (terr[t] == hipSuccess)
-                    terr[t] = hipMemcpyAsync((uint8_t*)c->dInput.p + sl0[k] * fstride, (uint8_t*)c->pinIn.p + sl0[k] * fstride,
-                                             (size_t)(sl1[k] - sl0[k]) * fstride, hipMemcpyHostToDevice, c->stream);
+            for (int k = 0; k < nsl; k++) {
+                const int m = sl1[k] - sl0[k];
+                stage_frames(sl0[k] + m * t / nthreads, sl0[k] + m * (t + 1) / nthreads);
+                if (arrived[k].fetch_add(1, std::memory_order_acq_rel) + 1 < nthreads || terr[t] != hipSuccess) continue;
+                const size_t off = (size_t)sl0[k] * fstride;
+                terr[t] = hipMemcpyAsync((uint8_t*)c->dInput.p + off, (uint8_t*)c->pinIn.p + off, (size_t)m * fstride,
+                                         hipMemcpyHostToDevice, c->stream);
                 if (terr[t] == hipSuccess && k + 1 == nLater) terr[t] = hipEventRecord(c->evIn, c->stream);
-                ticket.store(k + 1, std::memory_order_release);  // (also after a failure: the others must not wait for ever)
             }
         };
         std::thread workers[ORB_STAGE_THREADS];

@@ -182,6 +182,30 @@ def test_extract_batch_threaded_staging(hip, oracle):
     c.close()
 
 
+@pytest.mark.parametrize("parts,threads", [("3", "3"), ("2", "16"), ("1", "2")])
+def test_extract_batch_slices_arrive_in_group_order(hip, oracle, monkeypatch, parts, threads):
+    """A host batch is copied in slices of a few frames on one stream, the later frame groups' slices first, and
+    those groups start on an event while the first group's frames are still being copied: several slices per
+    group, more threads than slices, a single group.  Every frame must equal its one-frame call."""
+    monkeypatch.setenv("ORBHIP_PARTS", parts)
+    monkeypatch.setenv("ORBHIP_STAGE_THREADS", threads)
+    n, w, h = 26, 640, 480
+    c = _ctx(hip, "fork", batch=n)
+    imgs = [synth_scene(w, h, frame_seed(5, f)) for f in range(n)]
+    for rep in range(2):  # the second call reuses staging that still holds the first call's frames
+        order = imgs if rep == 0 else imgs[::-1]
+        res = c.extract_batch(order)
+        for f in (0, 7, 8, 9, 15, 16, 24, 25):
+            k1, d1 = c.extract(order[f])
+            assert_kps_equal(res[f][0], k1, "frame %d" % f)
+            np.testing.assert_array_equal(res[f][1], d1)
+    e = oracle.Extractor(1000, 1.2, 8, 20, 7, PRESETS["fork"])
+    ko, do = e.extract(imgs[0])
+    assert_kps_equal(res[n - 1][0], ko, "last frame of the reversed batch")
+    np.testing.assert_array_equal(res[n - 1][1], do)
+    c.close()
+
+
 def test_extract_with_plain_division(hip, oracle, monkeypatch):
     """The kernels divide by workgroup-uniform numbers through multipliers the host prepares, and fall back to
     ordinary division where a multiplier would not be exact; ORBHIP_PLAIN_DIVISION forces the fallback."""
