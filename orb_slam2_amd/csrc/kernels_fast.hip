@@ -37,6 +37,8 @@ struct TileSmall {
 struct TileLarge {
     static constexpr int TILE_PITCH = 72, TILE_ROWS = 66, SCORE_PITCH = 64, SCORE_ROWS = 62, MAX_W = 59, MAX_H = 59, WAVES_PER_SIMD = 4, CLASS = 1;
 };
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 #define CORN_CAP 256                                    // corners listed per cell for the suppression pass
 
 static __device__ __forceinline__ void wave_lds_sync() {
@@ -209,23 +211,37 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
                           xa + 4 * nd <= (level == 0 ? L.w : pitch);
     const int off = fastLoad ? tx0 - xa : 0;
     if (fastLoad) {
-        // lane = (row within a pass, dword); a pass covers 64 / nd rows.  All of a lane's loads are issued
-        // before the first one is awaited: one after the other they would make up most of the wavefront's life.
-        constexpr int RPP_MIN = 64 / (TILE_PITCH / 4), MAX_PASSES = (TILE_ROWS + RPP_MIN - 1) / RPP_MIN;
-        const int rpp = orb_div_small(64, nd);
-        const int rr = orb_div_small(lane, nd), d = lane - rr * nd;
-        if (rr < rpp) {
-            const uint8_t* src = img + (int64_t)(Y0 - 3 + rr) * pitch + xa + 4 * d;
-            uint32_t* dst = (uint32_t*)&tile[rr * TILE_PITCH + 4 * d];
-            const int64_t srcStep = (int64_t)rpp * pitch;
-            const int dstStep = rpp * (TILE_PITCH / 4);
+        // lane = (row within a pass, dword): COLS dword columns (lanes beyond the tile's width idle), 64 / COLS
+        // rows per pass.  All of a lane's loads are issued before the first one is awaited: one after the other
+        // they would make up most of the wavefront's life.  Straight-line code with wavefront-uniform row
+        // numbers: a pass starts at row min(k RP, th - RP), so the last ones fetch and store rows the earlier
+        // ones already did (same bytes to the same place) instead of being cut short or skipped; the row's
+        // address is scalar arithmetic, a lane adds its constant part (one vector instruction per store, none
+        // per load).
+        constexpr int COLS = TILE_PITCH / 4 <= 16 ? 16 : 32, RP = 64 / COLS;
+        constexpr int MAX_PASSES = (TG::MAX_H + 6 + RP - 1) / RP;
+        static_assert(TILE_PITCH / 4 <= COLS && RP <= 7, "a pass holds whole rows; a tile is at least 7 rows high (one pixel and its halo)");
+        const int rl = lane / COLS, d = lane & (COLS - 1);
+        if (d < nd) {
+            const uint8_t* base = img + (int64_t)(Y0 - 3) * pitch + xa;
+            const unsigned lo = __umul24((unsigned)rl, (unsigned)pitch) + 4u * (unsigned)d;
+            // the lane's part of the LDS address, opaque to the compiler (left to itself it adds the row numbers
+            // first and multiplies per lane, in 64 bits)
+            unsigned ldsLane = (unsigned)(uintptr_t)(lds_u8*)tile + (unsigned)(rl * TILE_PITCH + 4 * d);
+            asm volatile("" : "+v"(ldsLane));
             uint32_t v[MAX_PASSES];
 #pragma unroll
-            for (int k = 0; k < MAX_PASSES; k++)
-                if (rr + k * rpp < th) v[k] = *(const uint32_t*)(src + k * srcStep);
+            for (int k = 0; k < MAX_PASSES; k++) {
+                const unsigned r0 = (unsigned)min(k * RP, th - RP);
+                v[k] = *(const uint32_t*)(base + (r0 * (unsigned)pitch + lo));  // (a tile's bytes lie within 2^32 of its first)
+            }
 #pragma unroll
-            for (int k = 0; k < MAX_PASSES; k++)
-                if (rr + k * rpp < th) dst[k * dstStep] = v[k];
+            for (int k = 0; k < MAX_PASSES; k++) {
+                const unsigned r0 = (unsigned)min(k * RP, th - RP);
+                unsigned ro = r0 * (unsigned)TILE_PITCH;
+                asm volatile("" : "+s"(ro));  // a scalar product and one 32-bit vector add, not a 64-bit multiply-add per lane
+                *(lds_u32*)(uintptr_t)(ldsLane + ro) = v[k];
+            }
         }
     } else {
         const uint8_t* src = img + (int64_t)(Y0 - 3) * pitch + tx0;
