@@ -8,6 +8,8 @@
 // is 8.8 fixed point.  Results therefore do not depend on the tiling.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "orb_internal.h"
 
 // Resize, both interpolation modes, separably.  One workgroup produces a 64x32 destination tile:
@@ -22,6 +24,8 @@
 // four adjacent pixels per thread, stored as one dword.  This is the order cv::resize itself works in,
 // so sharing the horizontal results between destination rows changes nothing.
 typedef float float2v __attribute__((ext_vector_type(2)));  // element-wise products and sums: v_pk_mul_f32 / v_pk_add_f32
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 // Vertically adjacent tiles one workgroup makes in turn (PAIR instances): two, or four in launches over many frames
 // (fewer, longer workgroups: -3 % at 512 frames; at 8 and 64 frames four were 15 and 10 % slower than two).
@@ -218,44 +222,103 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
         return;
     }
 
-    int y0 = by * (tilesPerWg * ORB_RS_TH);
-    int sy0, nrows;
-    rows_of(y0, &sy0, &nrows);
-    uint32_t held[RS_STAGE_REGS];
+    // Staging of a tile, PAIR instances.  On 4-byte-aligned sources whose tile rows are at most 32 dwords a thread
+    // is (row within a pass of eight, dword) and a pass starts at row min(8 k, nrows - 8): the row numbers are the
+    // same for all lanes of a wavefront, so a row's address is scalar arithmetic plus the thread's constant part --
+    // one vector instruction per load and per store, no branches; the last passes fetch and store rows the earlier
+    // ones already did (same bytes to the same place) instead of being cut short.  Threads whose dword straddles
+    // the image width (caller's level 0 only) fetch theirs byte by byte afterwards.  Other sources keep the general
+    // mapping (rr, d) with its per-row tests.
+    const bool rowsUniform = aligned && nd <= 32;
+    const int rl = t >> 5, dd = t & 31;
+    const int colU = c.sxa + 4 * dd;
+    const bool activeU = dd < nd;
+    const bool dwordOkU = colU + 3 < sw || (srcPadded && colU + 4 <= sstride);
+    // (the two mappings run as two instances of the tile loop: were they merged after every fetch, the merge would
+    // wait for the loads it has to copy, and the point of fetching ahead would be lost)
+    auto tile_loop = [&](auto uniformTag) {
+        constexpr bool UNI = decltype(uniformTag)::value;
+        auto fetch_tile = [&](int fy0, int fn, uint32_t (&held)[RS_STAGE_REGS]) {
+            if (UNI) {
+                if (activeU && dwordOkU) {
+                    const unsigned lo = __umul24((unsigned)min(rl, fn - 1), (unsigned)sstride) + (unsigned)colU;
 #pragma unroll
-    for (int k = 0; k < RS_STAGE_REGS; k++) {
-        const int r = rr + k * rpp;
-        held[k] = (stager && r < nrows) ? fetch(sy0, r) : 0u;
-    }
-    for (int s = 0; s < tilesPerWg; s++) {
+                    for (int k = 0; k < RS_STAGE_REGS; k++) {
+                        const unsigned r0 = (unsigned)max(0, min(8 * k, fn - 8));
+                        held[k] = *(const uint32_t*)(S + (((unsigned)fy0 + r0) * (unsigned)sstride + lo));
+                    }
+                }
+            } else {
 #pragma unroll
-        for (int k = 0; k < RS_STAGE_REGS; k++) {
-            const int r = rr + k * rpp;
-            if (stager && r < nrows) *(uint32_t*)&c.tile[r * tp + 4 * d] = held[k];
-        }
-        stage_taps(y0);
-        __syncthreads();
-        // the second tile's rows are requested now and awaited after the first tile is done
-        const int ny0 = y0 + ORB_RS_TH;
-        const bool more = s + 1 < tilesPerWg && ny0 < dh;
-        int nsy0 = 0, nnrows = 0;
-        if (more) {
-            rows_of(ny0, &nsy0, &nnrows);
-#pragma unroll
-            for (int k = 0; k < RS_STAGE_REGS; k++) {
-                const int r = rr + k * rpp;
-                held[k] = (stager && r < nnrows) ? fetch(nsy0, r) : 0u;
+                for (int k = 0; k < RS_STAGE_REGS; k++) {
+                    const int r = rr + k * rpp;
+                    held[k] = (stager && r < fn) ? fetch(fy0, r) : 0u;
+                }
             }
+        };
+        auto store_tile = [&](int fy0, int fn, const uint32_t (&held)[RS_STAGE_REGS]) {
+            if (UNI) {
+                if (!activeU) return;
+                const int rlc = min(rl, fn - 1);
+                // the thread's part of the LDS address, opaque to the compiler (left to itself it adds the row
+                // numbers first and multiplies per lane)
+                unsigned ldsLane = (unsigned)(uintptr_t)(lds_u8*)c.tile + (unsigned)(rlc * tp + 4 * dd);
+                asm volatile("" : "+v"(ldsLane));
+                if (dwordOkU) {
+#pragma unroll
+                    for (int k = 0; k < RS_STAGE_REGS; k++) {
+                        unsigned ro = (unsigned)max(0, min(8 * k, fn - 8)) * (unsigned)tp;
+                        asm volatile("" : "+s"(ro));
+                        *(lds_u32*)(uintptr_t)(ldsLane + ro) = held[k];
+                    }
+                } else {  // a dword that straddles the image width: fetched now, byte by byte
+                    for (int k = 0; k < RS_STAGE_REGS; k++) {
+                        const int r0 = max(0, min(8 * k, fn - 8));
+                        const uint8_t* p = S + (((unsigned)(fy0 + r0 + rlc)) * (unsigned)sstride + (unsigned)colU);
+                        uint32_t v = 0u;
+                        for (int i = 0; i < 4; i++)
+                            if (colU + i < sw) v |= (uint32_t)p[i] << (8 * i);
+                        *(lds_u32*)(uintptr_t)(ldsLane + (unsigned)(r0 * tp)) = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < RS_STAGE_REGS; k++) {
+                    const int r = rr + k * rpp;
+                    if (stager && r < fn) *(uint32_t*)&c.tile[r * tp + 4 * d] = held[k];
+                }
+            }
+        };
+
+        int y0 = by * (tilesPerWg * ORB_RS_TH);
+        int sy0, nrows;
+        rows_of(y0, &sy0, &nrows);
+        uint32_t held[RS_STAGE_REGS];
+        fetch_tile(sy0, nrows, held);
+        for (int s = 0; s < tilesPerWg; s++) {
+            store_tile(sy0, nrows, held);
+            stage_taps(y0);
+            __syncthreads();
+            // the second tile's rows are requested now and awaited after the first tile is done
+            const int ny0 = y0 + ORB_RS_TH;
+            const bool more = s + 1 < tilesPerWg && ny0 < dh;
+            int nsy0 = 0, nnrows = 0;
+            if (more) {
+                rows_of(ny0, &nsy0, &nnrows);
+                fetch_tile(nsy0, nnrows, held);
+            }
+            rs_horizontal<AREA, NT>(c, txa, txl, nrows);
+            __syncthreads();
+            rs_vertical<AREA, NT>(c, s_mem, t, x0, y0, sy0, D, dw, dh, dpitch);
+            if (!more) break;
+            __syncthreads();  // tile, horizontal results and taps are free again
+            y0 = ny0;
+            sy0 = nsy0;
+            nrows = nnrows;
         }
-        rs_horizontal<AREA, NT>(c, txa, txl, nrows);
-        __syncthreads();
-        rs_vertical<AREA, NT>(c, s_mem, t, x0, y0, sy0, D, dw, dh, dpitch);
-        if (!more) break;
-        __syncthreads();  // tile, horizontal results and taps are free again
-        y0 = ny0;
-        sy0 = nsy0;
-        nrows = nnrows;
-    }
+    };
+    if (rowsUniform) tile_loop(std::true_type{});
+    else tile_loop(std::false_type{});
 }
 
 static __device__ __forceinline__ int reflect101(int i, int n) {
@@ -357,7 +420,8 @@ static int launch_resize(bool area, int ntaps, const uint8_t* src, int sw, int s
     }
     const int tilesY = (dh + ORB_RS_TH - 1) / ORB_RS_TH;
     // two tiles per workgroup when one tile is at most RS_STAGE_REGS dwords per thread (any level ratio up to ~1.5)
-    const int rowsPerPass = 256 / (tp / 4);
+    // (tile rows of at most 32 dwords may be staged eight rows per pass, see the kernel)
+    const int rowsPerPass = tp / 4 <= 32 ? 8 : 256 / (tp / 4);
     const bool pair = (rows + rowsPerPass - 1) / rowsPerPass <= RS_STAGE_REGS && tilesY > 1;
     const int tilesX = (dw + ORB_RS_TW - 1) / ORB_RS_TW;
     const int tilesPerWg = !pair ? 1 : nframes >= RS_MANY_FRAMES ? RS_TILES_PER_WG_MANY : RS_TILES_PER_WG;

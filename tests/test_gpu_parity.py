@@ -339,6 +339,38 @@ def test_extract_unaligned_rows(hip, oracle):
     c.close()
 
 
+def test_extract_width_off_four_in_aligned_rows(hip, oracle):
+    """Aligned rows (stride 640, frames 640 x 480 bytes apart) that hold 637, 638 or 639 pixels: the last dword of a
+    row straddles the image width, the bytes beyond it belong to no frame (here: 255, which would show).  A batch of
+    nine takes the batch kernels (whose staging patches such dwords byte by byte), one frame the few-frames path."""
+    import torch
+
+    n, h = 9, 480
+    for w in (637, 638, 639):
+        c = hip.Context(1000, 1.2, 8, 20, 7, w, h, n, 0, PRESETS["fork"])
+        e = oracle.Extractor(1000, 1.2, 8, 20, 7, PRESETS["fork"])
+        imgs = np.stack([synth_scene(w, h, frame_seed(9, 3 * w + f)) for f in range(n)])
+        buf = torch.full((n, h, 640), 255, dtype=torch.uint8, device="cuda")
+        buf[:, :, :w] = torch.from_numpy(imgs).cuda()
+        d_imgs = buf[:, :, :w]
+        cap = c.cap
+        for nb in (n, 1):
+            d_kps = torch.zeros((nb, cap, 28), dtype=torch.uint8, device="cuda")
+            d_desc = torch.zeros((nb, cap, 32), dtype=torch.uint8, device="cuda")
+            d_cnt = torch.zeros(nb, dtype=torch.int32, device="cuda")
+            c.extract_batch_device(d_imgs[:nb], d_kps, d_desc, d_cnt)
+            torch.cuda.synchronize()
+            c.check_last_batch()
+            cnt = d_cnt.cpu().numpy()
+            for f in ((0, n // 2, n - 1) if nb == n else (0,)):
+                ko, do = e.extract(imgs[f])
+                kg = d_kps[f, : cnt[f]].cpu().numpy().view(hip.KP_DTYPE).reshape(-1)
+                assert_kps_equal(kg, ko, "width %d, batch %d, frame %d" % (w, nb, f))
+                np.testing.assert_array_equal(d_desc[f, : cnt[f]].cpu().numpy(), do)
+                np.testing.assert_array_equal(c.pyramid_level(f, 1), e.level(1), err_msg="level 1, width %d" % w)
+        c.close()
+
+
 def test_empty_and_invalid_inputs(hip):
     c = _ctx(hip, "fork")
     k, d = c.extract(np.zeros((0, 0), np.uint8))
