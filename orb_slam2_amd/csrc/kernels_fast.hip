@@ -50,9 +50,10 @@ static __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Number of lanes below this one whose bit is set in a wavefront mask (two instructions).
-static __device__ __forceinline__ int lane_rank(unsigned long long m) {
-    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+// base + the number of lanes below this one whose bit is set in a wavefront mask (two instructions: the count
+// instructions add their third operand).
+static __device__ __forceinline__ int lane_rank(unsigned long long m, int base = 0) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)base));
 }
 
 // Three-input minimum / maximum as single instructions.  Written as min(a, min(b, c)) the compiler shares
@@ -154,7 +155,7 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
                                                                int* __restrict__ cellCount) {
     constexpr int TILE_PITCH = TG::TILE_PITCH, TILE_ROWS = TG::TILE_ROWS, SCORE_PITCH = TG::SCORE_PITCH, SCORE_ROWS = TG::SCORE_ROWS;
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[FAST_WAVES][TILE_ROWS * TILE_PITCH];
-    __shared__ __attribute__((aligned(16))) uint8_t s_score[FAST_WAVES][SCORE_ROWS * SCORE_PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t s_score[FAST_WAVES][(SCORE_ROWS * SCORE_PITCH + 15) / 16 * 16];
     __shared__ uint16_t s_cand[FAST_WAVES][128];
     __shared__ uint16_t s_corn[FAST_WAVES][CORN_CAP];
     // the wavefront index is the same in all 64 lanes: telling the compiler so keeps everything derived from
@@ -251,8 +252,12 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
     }
     tile += off;  // tile pixel (r, c) is tile[r * TILE_PITCH + c] from here on
     {
-        uint32_t* s32 = (uint32_t*)score;
-        for (int k = lane; k < (ch + 2) * SCORE_PITCH / 4; k += 64) s32[k] = 0u;  // rows 0 .. ch+1 are read
+        // the whole score tile, sixteen bytes per lane and step (rows 0 .. ch+1 are read)
+        constexpr int N16 = (SCORE_ROWS * SCORE_PITCH + 15) / 16;
+        uint4* s128 = (uint4*)score;
+#pragma unroll
+        for (int k = 0; k < (N16 + 63) / 64; k++)
+            if (k * 64 + 64 <= N16 || lane < N16 - k * 64) s128[k * 64 + lane] = make_uint4(0u, 0u, 0u, 0u);
     }
     wave_lds_sync();
 
@@ -293,7 +298,7 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
             }
             const unsigned long long m = __ballot(corner);
             if (corner) {
-                const int pos = nCorn + lane_rank(m);
+                const int pos = lane_rank(m, nCorn);
                 if (pos < CORN_CAP) corn[pos] = (uint16_t)q;
             }
             nCorn += __popcll(m);
@@ -311,7 +316,7 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
                 const int m1 = max(min(pS, pN), min(pE, pW)), m2 = min(max(pS, pN), max(pE, pW));
                 const bool pass = max(v - m1, m2 - v) > thLane;
                 const unsigned long long m = __ballot(pass);
-                if (pass) cand[(tail + lane_rank(m)) & 127] = (uint16_t)q;
+                if (pass) cand[lane_rank(m, tail) & 127] = (uint16_t)q;
                 tail += __popcll(m);
                 if (tail - head >= 64) score_chunk(64);
             };
@@ -361,7 +366,7 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
                     px = q & 255;
                     py = q >> 8;
                 }
-                const int pos = run + lane_rank(b);
+                const int pos = lane_rank(b, run);
                 const int sc = score[(py + 1) * SCORE_PITCH + px + 1];
                 if (pos < cellCap) out[pos] = (uint32_t)px | ((uint32_t)py << 8) | ((uint32_t)sc << 16);
             }
