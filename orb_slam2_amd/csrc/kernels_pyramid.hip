@@ -54,13 +54,18 @@ static __device__ __forceinline__ void rs_horizontal(const RsTileCtx& c, const O
         // and buf + pixel * 0 == buf exactly; what lies under them is some byte of the LDS allocation).
         const int b0 = txa.si[0] - c.sxa;
         const int sh = b0 & 3;
-        const uint32_t* rowp = (const uint32_t*)c.tile + (b0 >> 2);
         const int rowStep = c.tp >> 2;
         // two staged rows at a time (the LDS regions hold one row more than any tile stages, so the
-        // partner of a last odd row exists); the first product needs no sum: 0 + x == x for x >= +0
-        for (int r = 2 * c.q; r < nrows; r += 8) {
-            const uint32_t* p0 = rowp + r * rowStep;
-            const uint32_t* p1 = p0 + rowStep;
+        // partner of a last odd row exists); the first product needs no sum: 0 + x == x for x >= +0.
+        // The two rows are walked with an LDS address each, kept apart from the compiler's view: as one address plus
+        // the row pitch it forms both addresses anew in every step.
+        unsigned a0 = (unsigned)(uintptr_t)(lds_u8*)c.tile + 4u * (unsigned)((b0 >> 2) + 2 * c.q * rowStep);
+        unsigned a1 = a0 + 4u * (unsigned)rowStep;
+        const unsigned aStep = 32u * (unsigned)rowStep;
+        float* out = c.bufF + 2 * c.q * ORB_RS_TW + c.dx;
+        for (int r = 2 * c.q; r < nrows; r += 8, a0 += aStep, a1 += aStep, out += 8 * ORB_RS_TW) {
+            const lds_u32* p0 = (const lds_u32*)(uintptr_t)a0;
+            const lds_u32* p1 = (const lds_u32*)(uintptr_t)a1;
             const uint32_t w0 = __builtin_amdgcn_alignbyte(p0[1], p0[0], sh);
             const uint32_t w1 = __builtin_amdgcn_alignbyte(p1[1], p1[0], sh);
             float2v px = {(float)(w0 & 255u), (float)(w1 & 255u)};
@@ -73,8 +78,9 @@ static __device__ __forceinline__ void rs_horizontal(const RsTileCtx& c, const O
                 px = float2v{(float)(w0 >> 24), (float)(w1 >> 24)};
                 buf = buf + px * txa.a[3];
             }
-            c.bufF[r * ORB_RS_TW + c.dx] = buf.x;
-            c.bufF[(r + 1) * ORB_RS_TW + c.dx] = buf.y;
+            out[0] = buf.x;
+            out[ORB_RS_TW] = buf.y;
+            asm volatile("" : "+v"(a0), "+v"(a1));  // (the two addresses stay what the loop carries)
         }
     } else {
         int* bufI = (int*)c.bufF;
@@ -93,6 +99,7 @@ static __device__ __forceinline__ void rs_vertical(const RsTileCtx& c, const voi
     const int cg = t & 15;
     const int x = x0 + 4 * cg;
     if (x >= dw) return;
+    const bool dwordRows = ((((unsigned long long)dstFrame) | (unsigned long long)(unsigned)dpitch) & 3ull) == 0;  // uniform
     const int* bufI = (const int*)c.bufF;
 #pragma unroll
     for (int row = t >> 4; row < ORB_RS_TH; row += 16) {
@@ -101,11 +108,12 @@ static __device__ __forceinline__ void rs_vertical(const RsTileCtx& c, const voi
         uint32_t outw = 0u;
         if (AREA) {
             // all NT taps, no early exit: an unused tap has weight 0 and names the row of the last used one
+            // (the staged taps name rows by their byte offset in the tile's horizontal results)
             const OrbAreaTap ty = ((const OrbAreaTap*)taps)[row];
             float2v s01, s23;
 #pragma unroll
             for (int j = 0; j < NT; j++) {
-                const float4 b = *(const float4*)&c.bufF[(ty.si[j] - sy0) * ORB_RS_TW + 4 * cg];
+                const float4 b = *(const float4*)((const uint8_t*)c.bufF + ty.si[j] + 16 * cg);
                 const float2v t01 = float2v{b.x, b.y} * ty.a[j], t23 = float2v{b.z, b.w} * ty.a[j];
                 s01 = (j == 0) ? t01 : s01 + t01;
                 s23 = (j == 0) ? t23 : s23 + t23;
@@ -126,8 +134,10 @@ static __device__ __forceinline__ void rs_vertical(const RsTileCtx& c, const voi
                 outw |= (uint32_t)(v & 255) << (8 * i);
             }
         }
-        uint8_t* D = dstFrame + (int64_t)y * dpitch + x;
-        if (x + 3 < dw && (((unsigned long long)D) & 3ull) == 0) {
+        // (a frame's bytes lie within 2^31 of its first: one 24-bit multiply-add on top of the uniform frame address;
+        // x is a multiple of four, so whether the four pixels sit on a dword is the same for every thread)
+        uint8_t* D = dstFrame + (__umul24((unsigned)y, (unsigned)dpitch) + (unsigned)x);
+        if (x + 3 < dw && dwordRows) {
             *(uint32_t*)D = outw;
         } else {
 #pragma unroll
@@ -195,10 +205,17 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
             if (col + i < sw) v |= (uint32_t)p[i] << (8 * i);
         return v;
     };
-    auto stage_taps = [&](int y0) {
+    // the tile's vertical taps; the area taps' source rows as byte offsets into the horizontal results of this tile
+    auto stage_taps = [&](int y0, int sy0) {
         if (t < ORB_RS_TH && y0 + t < dh) {
-            if (AREA) ((OrbAreaTap*)s_mem)[t] = ((const OrbAreaTap*)ytab)[y0 + t];
-            else ((OrbLinTap*)s_mem)[t] = ((const OrbLinTap*)ytab)[y0 + t];
+            if (AREA) {
+                OrbAreaTap ty = ((const OrbAreaTap*)ytab)[y0 + t];
+#pragma unroll
+                for (int j = 0; j < ORB_MAX_TAPS; j++) ty.si[j] = (ty.si[j] - sy0) * (ORB_RS_TW * 4);
+                ((OrbAreaTap*)s_mem)[t] = ty;
+            } else {
+                ((OrbLinTap*)s_mem)[t] = ((const OrbLinTap*)ytab)[y0 + t];
+            }
         }
     };
     auto rows_of = [&](int y0, int* sy0, int* nrows) {
@@ -212,7 +229,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
         const int y0 = by * ORB_RS_TH;
         int sy0, nrows;
         rows_of(y0, &sy0, &nrows);
-        stage_taps(y0);
+        stage_taps(y0, sy0);
         if (stager)
             for (int r = rr; r < nrows; r += rpp) *(uint32_t*)&c.tile[r * tp + 4 * d] = fetch(sy0, r);
         __syncthreads();
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
         fetch_tile(sy0, nrows, held);
         for (int s = 0; s < tilesPerWg; s++) {
             store_tile(sy0, nrows, held);
-            stage_taps(y0);
+            stage_taps(y0, sy0);
             __syncthreads();
             // the second tile's rows are requested now and awaited after the first tile is done
             const int ny0 = y0 + ORB_RS_TH;
@@ -405,6 +422,10 @@ static int launch_resize(bool area, int ntaps, const uint8_t* src, int sw, int s
                          hipStream_t st, bool srcPadded) {
     if ((int64_t)sh * sstride > 0x7fffffffll || sh >= (1 << 24) || sstride >= (1 << 24)) {
         orb_set_error("resize: a source frame of %d rows of %d bytes is beyond the kernel's 32-bit row offsets", sh, sstride);
+        return ORB_ERR_UNSUPPORTED;
+    }
+    if ((int64_t)dh * dpitch > 0x7fffffffll || dh >= (1 << 24) || dpitch >= (1 << 24)) {
+        orb_set_error("resize: a destination frame of %d rows of %d bytes is beyond the kernel's 32-bit row offsets", dh, dpitch);
         return ORB_ERR_UNSUPPORTED;
     }
     const uint64_t scaleX = orb_resize_scale_fx(sw, dw), scaleY = orb_resize_scale_fx(sh, dh);
