@@ -27,11 +27,13 @@
 #define HB_P 40    // horizontal sums (16 bit) of a row pair per column of those groups: one dword each
 #endif
 #define HB_PAIRS 22  // row pairs (0,1) .. (42,43); row 43 does not exist, its sums meet weight 0 only
-#define HB_SLOTS 18  // row pairs whose sums are held in LDS at a time (the passes work on half the window in turn)
+#define HB_FIRST 12  // pairs made by the first horizontal phase (source rows 0..23)
 #define BL_N 37
-#ifndef BL_P
-#define BL_P 44
-#endif
+#define HB_BYTES (HB_PAIRS * HB_P * 4)
+#define RAW_OFF (HB_BYTES - 2 * HB_FIRST * RAW_P)
+#define LDS_BYTES (RAW_OFF + (RAW_N + 1) * RAW_P)
+static_assert(RAW_OFF >= HB_FIRST * HB_P * 4 && RAW_OFF % 16 == 0 && LDS_BYTES % 16 == 0,
+              "the source window starts behind the first phase's sums, on a 16-byte boundary");
 
 // the 256 test pairs of src/ORBextractor.cc:105-362 as (x0, x1, y0, y1), kept as floats for the rotation
 __constant__ __attribute__((aligned(16))) float c_pattern[256 * 4] = {
@@ -135,6 +137,8 @@ static __device__ __forceinline__ void wave_lds_sync() {
 }
 
 typedef float float2v __attribute__((ext_vector_type(2)));  // element-wise products and sums: v_pk_mul_f32 / v_pk_add_f32
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
 // sum of the two 16-bit products of a and b, plus c (v_dot2_u32_u16)
 static __device__ __forceinline__ uint32_t dot2_u16(uint32_t a, uint32_t b, uint32_t c) {
@@ -171,8 +175,10 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
                                                              orb_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
                                                              int capPerFrame, int* __restrict__ nOut,
                                                              int* __restrict__ error, int* __restrict__ status) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_raw[DESC_WAVES][(RAW_N + 1) * RAW_P];  // + the partner row of row 42
-    __shared__ __attribute__((aligned(16))) uint32_t s_hb[DESC_WAVES][HB_SLOTS * HB_P];
+    // One block per wavefront: the horizontal sums of the 22 row pairs (HB_BYTES), and the source window (44 rows: + the
+    // partner row of row 42) placed so that its rows 0..23 are the tail of that region and rows 24..43 lie behind it --
+    // the sums of pairs 12..21, made from rows 24..43, overwrite rows the pairs 0..11 have consumed.
+    __shared__ __attribute__((aligned(16))) uint8_t s_lds[DESC_WAVES][LDS_BYTES];
     // the wavefront index is the same in all 64 lanes: telling the compiler so keeps everything derived from
     // it (frame, level, keypoint, window addresses, loop bounds) in scalar registers
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -220,10 +226,8 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
         img = pyr + L.off + (int64_t)frame * L.frameStride;
         pitch = L.pitch;
     }
-    uint8_t* raw = s_raw[wave];
-    uint32_t* hb = s_hb[wave];
-    uint8_t* bl = s_raw[wave];  // the blurred window (37 x 44 bytes) takes the place of the source window, which the
-                                // horizontal pass has consumed by the time the vertical pass writes it
+    uint8_t* raw = s_lds[wave] + RAW_OFF;
+    uint32_t* hb = (uint32_t*)s_lds[wave];
 
     // 43x43 source window.  On 4-byte-aligned rows it is fetched as whole dwords (12 per row, the window then starts
     // `off` bytes into the LDS row): interior keypoints as they are; keypoints whose window leaves the level by its
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     // 32 * sum I), come from the table the host built for the context's umax (icm, fetched above).
     int m10 = 0, m01 = 0;
     {
-        const uint32_t* raw32 = (const uint32_t*)s_raw[wave];
+        const uint32_t* raw32 = (const uint32_t*)raw;
         int m00 = 0;
         if (icRow < 7) {
 #pragma unroll
@@ -330,10 +334,11 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     m01 = wave_sum(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // Blur of the 37x37 window the pattern can reach.  Both passes work on the aligned columns of the
-    // LDS rows, four at a time from whole dwords: horizontal 8.8 sums (16 bit), then vertical with one
-    // rounding (taps against pairs of rows with v_dot2_u32_u16).  Aligned columns outside [off + 3, off + 39] hold sums of bytes that are not part of
-    // the window; nothing reads them.
+    // Blur of the 37x37 window the pattern can reach, evaluated where the pattern samples it.  The horizontal pass
+    // works on the aligned columns of the LDS rows, four at a time from whole dwords, and leaves 8.8 sums (16 bit) for
+    // all 44 rows; the vertical taps are then applied at the 512 sample points only (two per lane and round), seven
+    // rows of sums against the taps with v_dot2_u32_u16 and one rounding -- the value the blurred level has there.
+    // Aligned columns outside [off + 3, off + 39] hold sums of bytes that are not part of the window; nothing reads them.
     const bool legacy = (g->quirks & ORB_Q_GAUSS_LEGACY) != 0;
     const uint32_t k0 = 18, k1 = 34, k2 = legacy ? 49 : 48, k3 = legacy ? 55 : 56;
     // taps k0 k1 k2 k3 k2 k1 k0 against the bytes of the dwords A (columns 4q-4..4q-1), B (4q..4q+3), C (4q+4..4q+7)
@@ -342,23 +347,17 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     const uint32_t wA1 = (k0 << 16) | (k1 << 24), wB1 = k2 | (k3 << 8) | (k2 << 16) | (k1 << 24), wC1 = k0;
     const uint32_t wA2 = k0 << 24, wB2 = k1 | (k2 << 8) | (k3 << 16) | (k2 << 24), wC2 = k1 | (k0 << 8);
     const uint32_t wB3 = k0 | (k1 << 8) | (k2 << 16) | (k3 << 24), wC3 = k2 | (k1 << 8) | (k0 << 16);
-    const uint32_t* raw32 = (const uint32_t*)s_raw[wave];
-    uint32_t* hb32 = (uint32_t*)hb;
+    const uint32_t* raw32 = (const uint32_t*)raw;
+    uint32_t* hb32 = hb;
     // lane = (row pair within a pass of six, group of four columns); lanes 60..63 idle.  The horizontal
-    // sums of rows 2p and 2p + 1 are stored side by side, one dword per column: the vertical pass then
-    // takes its seven rows as four such dwords whatever the parity of its first row, with no shuffling.
+    // sums of rows 2p and 2p + 1 are stored side by side, one dword per column: seven consecutive rows are then
+    // four such dwords whatever the parity of the first one.
     const int rr = lane_div<HGROUPS>(lane), qi = lane - rr * HGROUPS;
-    const int q = ((off + 3) >> 2) + qi;  // the group's place in the LDS rows of the source and blurred windows
-    // The two passes take turns, half of the window each, so that the sums of only 13 row pairs have to be held at a
-    // time (HB_SLOTS slots of LDS instead of 22: 5.0 KB per wavefront, 32 wavefronts per CU instead of 29):
-    //   A  horizontal sums of row pairs 0..11 -> slots pair + 6, pairs 9..11 also -> slots 0..2
-    //   B  blurred rows 0..17 (they need pairs 0..11), written over source rows 0..16, which A has consumed
-    //   C  horizontal sums of row pairs 12..21 -> slots pair - 9 = 3..12 (over the sums B has consumed)
-    //   D  blurred rows 18..36 (pairs 9..21 = slots 0..12), written over the source rows C has consumed
+    const int q = ((off + 3) >> 2) + qi;  // the group's place in the LDS rows of the source window
     // LDS operations of the one wavefront execute in program order; the syncs only keep the compiler from moving
     // them across.
     const int back = q > 0 ? -1 : 0;
-    auto hpass = [&](int pr, int slot, bool alsoLow) {
+    auto hpass = [&](int pr) {
         const uint32_t* p = raw32 + 2 * pr * (RAW_P / 4) + q;
         uint32_t o[2][4];
 #pragma unroll
@@ -376,75 +375,48 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
         e.y = (o[1][1] << 16) + o[0][1];
         e.z = (o[1][2] << 16) + o[0][2];
         e.w = (o[1][3] << 16) + o[0][3];
-        *(uint4*)(hb32 + slot * HB_P + 4 * qi) = e;
-        if (alsoLow && pr >= 9) *(uint4*)(hb32 + (pr - 9) * HB_P + 4 * qi) = e;
+        *(uint4*)(hb32 + pr * HB_P + 4 * qi) = e;
     };
-    uint32_t* bl32 = (uint32_t*)bl;
-    // tap pairs against (row 2p, row 2p + 1) for an even first row r = 2p, and for an odd one r = 2p + 1
-    const uint32_t wE0 = k0 | (k1 << 16), wE1 = k2 | (k3 << 16), wE2 = k2 | (k1 << 16), wE3 = k0;
-    const uint32_t wO0 = k0 << 16, wO1 = k1 | (k2 << 16), wO2 = k3 | (k2 << 16), wO3 = k1 | (k0 << 16);
-    // HROWS is even: all rows of a lane have the parity of its first one
-    static_assert(HROWS % 2 == 0, "the tap words are chosen once per lane");
-    const bool odd = (rr & 1) != 0;
-    const uint32_t w0 = odd ? wO0 : wE0, w1 = odd ? wO1 : wE1, w2 = odd ? wO2 : wE2, w3 = odd ? wO3 : wE3;
-    auto vpass = [&](int r, int slot) {  // blurred row r from the four slots that hold rows r .. r + 7
-        const uint32_t* p = hb32 + __umul24((unsigned)slot, HB_P) + 4 * qi;
-        const uint4 e0 = *(const uint4*)p, e1 = *(const uint4*)(p + HB_P), e2 = *(const uint4*)(p + 2 * HB_P),
-                    e3 = *(const uint4*)(p + 3 * HB_P);
-        const uint32_t c0[4] = {e0.x, e0.y, e0.z, e0.w}, c1[4] = {e1.x, e1.y, e1.z, e1.w};
-        const uint32_t c2[4] = {e2.x, e2.y, e2.z, e2.w}, c3[4] = {e3.x, e3.y, e3.z, e3.w};
-        uint32_t v[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            v[c] = dot2_u16(c0[c], w0, 32768u);
-            v[c] = dot2_u16(c1[c], w1, v[c]);
-            v[c] = dot2_u16(c2[c], w2, v[c]);
-            v[c] = dot2_u16(c3[c], w3, v[c]);
-        }
-        uint32_t packed;
-        if (legacy) {  // these taps sum to 257: the rounded value can pass 255
-            packed = 0;
-#pragma unroll
-            for (int c = 0; c < 4; c++) packed |= min(v[c] >> 16, 255u) << (8 * c);
-        } else {       // taps summing to 256 cannot: (255 * 256 * 256 + 2^15) >> 16 == 255; the pixel is byte 2
-            packed = __builtin_amdgcn_perm(__builtin_amdgcn_perm(v[3], v[2], 0x0c0c0602u),
-                                           __builtin_amdgcn_perm(v[1], v[0], 0x0c0c0602u), 0x05040100u);
-        }
-        bl32[r * (BL_P / 4) + q] = packed;
-    };
-    static_assert(HROWS == 6 && HB_PAIRS == 22 && BL_N == 37 && HB_SLOTS >= 18, "the phases below are laid out for these");
+    static_assert(HROWS == 6 && HB_PAIRS == 22 && HB_FIRST == 12 && BL_N == 37, "the phases below are laid out for these");
     if (rr < HROWS) {
-        hpass(rr, rr + 6, false);           // A: pairs 0..5
-        hpass(rr + 6, rr + 12, true);       //    pairs 6..11
+        hpass(rr);           // pairs 0..5
+        hpass(rr + 6);       // pairs 6..11
+    }
+    wave_lds_sync();         // source rows 0..23 are consumed: the sums of pairs 12..21 may take their place
+    if (rr < HROWS) {
+        hpass(rr + 12);      // pairs 12..17
+        if (rr + 18 < HB_PAIRS) hpass(rr + 18);  // pairs 18..21
     }
     wave_lds_sync();
-    if (rr < HROWS) {
-#pragma unroll 1
-        for (int r = rr; r < 18; r += HROWS) vpass(r, (r >> 1) + 6);  // B
-    }
-    wave_lds_sync();
-    if (rr < HROWS) {
-        hpass(rr + 12, rr + 3, false);      // C: pairs 12..17
-        if (rr + 18 < HB_PAIRS) hpass(rr + 18, rr + 9, false);  // pairs 18..21
-    }
-    wave_lds_sync();
-    if (rr < HROWS) {
-#pragma unroll 1
-        for (int r = rr + 18; r < BL_N; r += HROWS) vpass(r, (r >> 1) - 9);  // D
-    }
-    wave_lds_sync();
-    bl += off + 3;  // blurred window pixel (r, c), c = 0..36, is bl[r * BL_P + c] from here on
 
     // rBRIEF: lane l of round r compares pair 64r + l; the ballot is descriptor bytes 8r..8r+7.
     const float factorPI = (float)(3.14159265358979323846 / 180.f);
     float a, b;
     sincos_portable(__fmul_rn(angle, factorPI), &b, &a);
-    // Rounding to the nearest integer, ties to even (cvRound), by adding 1.5 * 2^23: the sum's low mantissa bits
-    // are 2^22 + the rounded value, for any |value| < 2^22.  The 24-bit multiply-add below takes those bits
-    // as they are; what the constant contributes is subtracted once, together with the window's centre.
+    // Rounding to the nearest integer, ties to even (cvRound), by adding 1.5 * 2^23: the sum's bits are those of the
+    // constant plus the rounded value, for any |value| < 2^22.  Window row and column of a sample point are those bits
+    // less (the constant's - 18).
     const float magic = 12582912.f;
-    const uint32_t magicBits = 0x4B400000u, magicLow = 0x400000u;
-    const uint32_t bias = magicLow * BL_P + magicBits - (18u * BL_P + 18u);
+    const uint32_t magicBits = 0x4B400000u;
+    // tap pairs against (row 2p, row 2p + 1) for an even first row r = 2p, and for an odd one r = 2p + 1
+    const uint32_t wE0 = k0 | (k1 << 16), wE1 = k2 | (k3 << 16), wE2 = k2 | (k1 << 16), wE3 = k0;
+    const uint32_t wO0 = k0 << 16, wO1 = k1 | (k2 << 16), wO2 = k3 | (k2 << 16), wO3 = k1 | (k0 << 16);
+    // Byte address of the sums of (row pair p, window column c): with yb and xb the bits of the rounded floats,
+    // row r = yb - (magicBits - 18) is the first of the seven rows and p = r >> 1; the constant is even, so r has
+    // yb's parity, and the low 24 bits of yb >> 1 are 0xA00000 - 9 + p: one shift, one 24-bit multiply-add and one
+    // shift-add, the constants folded into `base`.
+    const uint32_t base = (uint32_t)(uintptr_t)(lds_u8*)hb + 4u * (uint32_t)((off + 3) & 3) - 4u * (magicBits - 18u) -
+                          (0xA00000u - 9u) * (4u * HB_P);
+    auto blurred_at = [&](uint32_t yBits, uint32_t xBits) -> uint32_t {
+        const bool odd = (yBits & 1u) != 0u;
+        const uint32_t addr = __umul24(yBits >> 1, 4u * HB_P) + ((xBits << 2) + base);
+        const lds_u32* p = (const lds_u32*)(uintptr_t)addr;
+        uint32_t v = dot2_u16(p[0], odd ? wO0 : wE0, 32768u);
+        v = dot2_u16(p[HB_P], odd ? wO1 : wE1, v);
+        v = dot2_u16(p[2 * HB_P], odd ? wO2 : wE2, v);
+        v = dot2_u16(p[3 * HB_P], odd ? wO3 : wE3, v);
+        return min(v >> 16, 255u);  // (the legacy taps sum to 257: the rounded value can pass 255; the others cannot)
+    };
     unsigned long long words[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -455,10 +427,8 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
         const float2v xs = {pt.x, pt.y}, ys = {pt.z, pt.w};
         const float2v fy = (xs * b + ys * a) + magic;
         const float2v fx = (xs * a - ys * b) + magic;
-        const uint32_t i0 = __umul24(__float_as_uint(fy.x), BL_P) + __float_as_uint(fx.x) - bias;
-        const uint32_t i1 = __umul24(__float_as_uint(fy.y), BL_P) + __float_as_uint(fx.y) - bias;
-        const int t0 = bl[i0];
-        const int t1 = bl[i1];
+        const uint32_t t0 = blurred_at(__float_as_uint(fy.x), __float_as_uint(fx.x));
+        const uint32_t t1 = blurred_at(__float_as_uint(fy.y), __float_as_uint(fx.y));
         words[r] = __ballot(t0 < t1);
     }
     if (lane == 0) {
