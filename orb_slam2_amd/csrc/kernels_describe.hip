@@ -6,9 +6,10 @@
 //
 // One wavefront per keypoint.  The 43x43 source window around the keypoint is
 // staged in LDS once; the 31x31 circular patch moments come from its centre,
-// and the blur is evaluated only on the 37x37 window the rotated sampling
-// pattern can reach (radius 18.4).  The blur is exact 8.8 fixed point, so this
-// equals blurring the whole level first.
+// and the blur is evaluated only where the rotated sampling pattern reads it:
+// horizontal sums for the window's rows, the vertical taps at the 512 sample
+// points (all within radius 18.4 of the keypoint).  The blur is exact 8.8
+// fixed point, so this equals blurring the whole level first.
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
