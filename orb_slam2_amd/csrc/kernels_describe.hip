@@ -166,6 +166,8 @@ static __device__ __forceinline__ int wave_sum(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// LEGACY: the Gaussian taps of OpenCV before 3.x (ORB_Q_GAUSS_LEGACY), which sum to 257 instead of 256.
+template <bool LEGACY>
 __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __restrict__ g,
                                                              const uint8_t* __restrict__ img0, int stride0,
                                                              int64_t frameStride0, const uint8_t* __restrict__ pyr,
@@ -340,8 +342,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
     // all 44 rows; the vertical taps are then applied at the 512 sample points only (two per lane and round), seven
     // rows of sums against the taps with v_dot2_u32_u16 and one rounding -- the value the blurred level has there.
     // Aligned columns outside [off + 3, off + 39] hold sums of bytes that are not part of the window; nothing reads them.
-    const bool legacy = (g->quirks & ORB_Q_GAUSS_LEGACY) != 0;
-    const uint32_t k0 = 18, k1 = 34, k2 = legacy ? 49 : 48, k3 = legacy ? 55 : 56;
+    constexpr uint32_t k0 = 18, k1 = 34, k2 = LEGACY ? 49 : 48, k3 = LEGACY ? 55 : 56;
     // taps k0 k1 k2 k3 k2 k1 k0 against the bytes of the dwords A (columns 4q-4..4q-1), B (4q..4q+3), C (4q+4..4q+7)
     // for the outputs at columns 4q + 0..3
     const uint32_t wA0 = (k0 << 8) | (k1 << 16) | (k2 << 24), wB0 = k3 | (k2 << 8) | (k1 << 16) | (k0 << 24);
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
         v = dot2_u16(p[HB_P], odd ? wO1 : wE1, v);
         v = dot2_u16(p[2 * HB_P], odd ? wO2 : wE2, v);
         v = dot2_u16(p[3 * HB_P], odd ? wO3 : wE3, v);
-        return min(v >> 16, 255u);  // (the legacy taps sum to 257: the rounded value can pass 255; the others cannot)
+        return LEGACY ? min(v >> 16, 255u) : v >> 16;  // (taps that sum to 257: the rounded value can pass 255)
     };
     unsigned long long words[4];
 #pragma unroll
@@ -454,9 +455,14 @@ __global__ __launch_bounds__(64 * DESC_WAVES) void k_describe(const OrbGeom* __r
 int orb_launch_describe(const OrbBatch& b) {
     const OrbGeom& g = *b.h_geom;
     const int64_t blocks = orb_xcd_grid(b.nframes, g.outCapFrame);
-    hipLaunchKernelGGL(k_describe, dim3((unsigned)blocks), dim3(64 * DESC_WAVES), 0, (hipStream_t)b.stream, b.d_geom,
-                       b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, b.nframes, b.d_selXY, b.d_selScore,
-                       b.d_levelCount, b.d_kps, b.d_desc, b.capPerFrame, b.d_nOut, b.d_error, b.d_status);
+    if (g.quirks & ORB_Q_GAUSS_LEGACY)
+        hipLaunchKernelGGL(k_describe<true>, dim3((unsigned)blocks), dim3(64 * DESC_WAVES), 0, (hipStream_t)b.stream, b.d_geom,
+                           b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, b.nframes, b.d_selXY, b.d_selScore,
+                           b.d_levelCount, b.d_kps, b.d_desc, b.capPerFrame, b.d_nOut, b.d_error, b.d_status);
+    else
+        hipLaunchKernelGGL(k_describe<false>, dim3((unsigned)blocks), dim3(64 * DESC_WAVES), 0, (hipStream_t)b.stream, b.d_geom,
+                           b.d_img0, b.stride0, b.frameStride0, b.d_pyr, b.frame0, b.nframes, b.d_selXY, b.d_selScore,
+                           b.d_levelCount, b.d_kps, b.d_desc, b.capPerFrame, b.d_nOut, b.d_error, b.d_status);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         orb_set_error("describe launch failed: %s", hipGetErrorString(e));
