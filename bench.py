@@ -76,6 +76,12 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip batch sweep, host path, single frame and other configurations")
     args = ap.parse_args()
 
+    # The one JSON line is all this program writes to its standard output: whatever libraries print there meanwhile
+    # (RCCL announces its version on the first collective) goes to standard error instead.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -473,7 +479,8 @@ def main():
             out.update(extras)
         if rehearse:
             out["rehearsal"] = "ranks share GPUs, gloo collectives: not a measurement"
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if grouped:
         dist.destroy_process_group()
 
