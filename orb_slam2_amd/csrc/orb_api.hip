@@ -1032,7 +1032,8 @@ extern "C" int orb_extract_batch(orb_ctx* c, const uint8_t* const* imgs, int n, 
         const int g1 = parts > 1 ? n / parts : 0;  // frames [g1, n) belong to the later groups
         const int per = (int)std::max<int64_t>(1, std::min<int64_t>(n, ORB_STAGE_SLICE_BYTES / fstride));
         int sl0[ORB_MAX_STAGE_SLICES], sl1[ORB_MAX_STAGE_SLICES], nsl = 0, nLater = 0;
-        const int perCapped = std::max(per, (n + ORB_MAX_STAGE_SLICES - 2) / (ORB_MAX_STAGE_SLICES - 1));
+        // (a slice holds at least n / 30 frames: the two runs below, each ending in a shorter slice, make at most 32)
+        const int perCapped = std::max(per, (n + ORB_MAX_STAGE_SLICES / 2 - 3) / (ORB_MAX_STAGE_SLICES / 2 - 2));
         for (int s0 = g1; s0 < n; s0 += perCapped) sl0[nsl] = s0, sl1[nsl++] = std::min(n, s0 + perCapped);
         nLater = g1 > 0 ? nsl : 0;
         for (int s0 = 0; s0 < g1; s0 += perCapped) sl0[nsl] = s0, sl1[nsl++] = std::min(g1, s0 + perCapped);
