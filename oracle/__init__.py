@@ -1,4 +1,6 @@
-"""CPU ORACLE — TEST INFRASTRUCTURE, NOT PRODUCT CODE.  PARITY UNPINNED.
+"""CPU ORACLE — TEST INFRASTRUCTURE, NOT PRODUCT CODE.  PARITY UNPINNED, with one exception: the
+bag-of-words bookkeeping (BowVector / FeatureVector) is checked against the reference's own two
+source files compiled here (oracle/ref_dbow2/Makefile -> oracle/_ref/libdbow2_ref.so).
 
 ctypes binding over oracle/liborb_oracle.so (built by oracle/Makefile from
 the C++ restatement in this directory).  Only tests/, __graft_entry__.smoke()
@@ -425,3 +427,41 @@ def search_for_triangulation(keys_un1, desc1, free1, fv1, keys_un2, desc2, free2
                                            _p(k2), _p(d2), _p(f2), len(k2), _p(b[0]), _p(b[1]), _p(b[2]), len(b[0]),
                                            _p(F), _p(ep), _p(sc), _p(sg), len(sc), int(mark_matched), int(check_ori), _p(match))
     return n, match[: len(k1)]
+
+
+def _bow_stream(fn, ids, weights, nids, scoring, weighting):
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    nids = np.ascontiguousarray(nids, dtype=np.int32)
+    weights = np.ascontiguousarray(weights, dtype=np.float64)
+    n = len(ids)
+    bi = np.zeros(max(n, 1), dtype=np.int32)
+    bv = np.zeros(max(n, 1), dtype=np.float64)
+    nodes = np.zeros(max(n, 1), dtype=np.int32)
+    offs = np.zeros(n + 1, dtype=np.int32)
+    idx = np.zeros(max(n, 1), dtype=np.int32)
+    nb, nn = C.c_int(0), C.c_int(0)
+    fn(_p(ids), _p(weights), _p(nids), n, int(scoring), int(weighting), _p(bi), _p(bv), C.byref(nb), _p(nodes), _p(offs),
+       _p(idx), C.byref(nn))
+    return (bi[: nb.value].copy(), bv[: nb.value].copy()), (
+        nodes[: nn.value].copy(), offs[: nn.value + 1].copy(), idx[: offs[nn.value]].copy())
+
+
+def bow_accumulate(ids, weights, nids, scoring, weighting):
+    """The bookkeeping half of TemplatedVocabulary::transform on a stream of per-feature (word id, weight, node id):
+    ((ids, values), (nodes, offsets, indices)), the oracle's restatement."""
+    return _bow_stream(lib().oro_bow_accumulate, ids, weights, nids, scoring, weighting)
+
+
+_REF_DBOW2 = None
+
+
+def ref_dbow2_available():
+    return os.path.exists(os.path.join(_DIR, "_ref", "libdbow2_ref.so"))
+
+
+def ref_bow_accumulate(ids, weights, nids, scoring, weighting):
+    """The same through the reference's own BowVector.cpp / FeatureVector.cpp, compiled by oracle/ref_dbow2/Makefile."""
+    global _REF_DBOW2
+    if _REF_DBOW2 is None:
+        _REF_DBOW2 = C.CDLL(os.path.join(_DIR, "_ref", "libdbow2_ref.so"))
+    return _bow_stream(_REF_DBOW2.ref_bow_accumulate, ids, weights, nids, scoring, weighting)

@@ -161,6 +161,8 @@ struct Vocabulary {  // TemplatedVocabulary<FORB::TDescriptor, FORB>
                    std::map<int, std::vector<unsigned> >& fv) const;
 };
 double scoreL1(const std::map<int, double>& v1, const std::map<int, double>& v2);
+void bowAccumulate(const int* ids, const double* weights, const int* nids, int n, int scoring, int weighting,
+                   std::map<int, double>& bow, std::map<int, std::vector<unsigned> >& fv);
 int searchByBoW(const KeyPoint* kfKeysUn, const uint8_t* kfDesc, const uint8_t* kfValid,
                 const std::map<int, std::vector<unsigned> >& kfFeat, const KeyPoint* fKeys, const uint8_t* fDesc, int nF,
                 const std::map<int, std::vector<unsigned> >& fFeat, float nnratio, bool checkOri, int* matchKF);

@@ -122,25 +122,24 @@ static bool mustNormalize(int scoring, int* norm) {  // ScoringObject.h:85-93 (L
     }
 }
 
-// TemplatedVocabulary.h:1136-1206 with BowVector::addWeight / addIfNotExist / normalize
-// (BowVector.cpp:40-95) and FeatureVector::addFeature (FeatureVector.cpp:37-52).
-void Vocabulary::transform(const uint8_t* desc, int n, int levelsup, std::map<int, double>& bow,
-                           std::map<int, std::vector<unsigned> >& fv) const {
+// The bookkeeping half of TemplatedVocabulary.h:1136-1206: what transform() does with the (word, weight, node)
+// triple of each feature - BowVector::addWeight / addIfNotExist / normalize (BowVector.cpp:40-95) and
+// FeatureVector::addFeature (FeatureVector.cpp:37-52).  tests/test_oracle_ref_dbow2.py runs the same streams
+// through those two reference files compiled as they are (oracle/_ref/libdbow2_ref.so).
+void bowAccumulate(const int* ids, const double* weights, const int* nids, int n, int scoring, int weighting,
+                   std::map<int, double>& bow, std::map<int, std::vector<unsigned> >& fv) {
     bow.clear();
     fv.clear();
-    if (nwords == 0) return;
     int norm = 0;
     const bool must = mustNormalize(scoring, &norm);
     const bool tf = weighting == 0 /*TF_IDF*/ || weighting == 1 /*TF*/;
     for (int i = 0; i < n; i++) {
-        int id, nid;
-        double w;
-        transformOne(desc + (size_t)i * 32, levelsup, &id, &w, &nid);
+        const double w = weights[i];
         if (w > 0) {
-            std::map<int, double>::iterator it = bow.find(id);
-            if (it == bow.end()) bow[id] = w;
+            std::map<int, double>::iterator it = bow.find(ids[i]);
+            if (it == bow.end()) bow[ids[i]] = w;
             else if (tf) it->second += w;
-            fv[nid].push_back((unsigned)i);
+            fv[nids[i]].push_back((unsigned)i);
         }
     }
     if (tf && !bow.empty() && !must) {
@@ -158,6 +157,18 @@ void Vocabulary::transform(const uint8_t* desc, int n, int levelsup, std::map<in
         if (s > 0.0)
             for (auto& e : bow) e.second /= s;
     }
+}
+
+// TemplatedVocabulary.h:1136-1206
+void Vocabulary::transform(const uint8_t* desc, int n, int levelsup, std::map<int, double>& bow,
+                           std::map<int, std::vector<unsigned> >& fv) const {
+    bow.clear();
+    fv.clear();
+    if (nwords == 0) return;
+    std::vector<int> ids((size_t)n), nids((size_t)n);
+    std::vector<double> ws((size_t)n);
+    for (int i = 0; i < n; i++) transformOne(desc + (size_t)i * 32, levelsup, &ids[i], &ws[i], &nids[i]);
+    bowAccumulate(ids.data(), ws.data(), nids.data(), n, scoring, weighting, bow, fv);
 }
 
 // L1Scoring::score, ScoringObject.cpp:23-68

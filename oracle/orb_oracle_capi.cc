@@ -275,6 +275,29 @@ void oro_voc_bow(void* h, const uint8_t* desc, int n, int levelsup, int* bowIds,
     }
     *nFvNodes = a;
 }
+// The same outputs from a stream of (word id, weight, node id) triples, one per feature, for a vocabulary of
+// the given scoring (0 L1 .. 5 dot product) and weighting (0 TF-IDF, 1 TF, 2 IDF, 3 binary) types.
+void oro_bow_accumulate(const int* ids, const double* weights, const int* nids, int n, int scoring, int weighting,
+                        int* bowIds, double* bowVals, int* nBow, int* fvNodes, int* fvOffsets, int* fvIdx, int* nFvNodes) {
+    std::map<int, double> bow;
+    std::map<int, std::vector<unsigned> > fv;
+    bowAccumulate(ids, weights, nids, n, scoring, weighting, bow, fv);
+    int i = 0;
+    for (auto& e : bow) {
+        bowIds[i] = e.first;
+        bowVals[i] = e.second;
+        i++;
+    }
+    *nBow = i;
+    int a = 0, o = 0;
+    fvOffsets[0] = 0;
+    for (auto& e : fv) {
+        fvNodes[a] = e.first;
+        for (unsigned f : e.second) fvIdx[o++] = (int)f;
+        fvOffsets[++a] = o;
+    }
+    *nFvNodes = a;
+}
 double oro_score_l1(const int* ids1, const double* vals1, int n1, const int* ids2, const double* vals2, int n2) {
     std::map<int, double> a, b;
     for (int i = 0; i < n1; i++) a[ids1[i]] = vals1[i];
