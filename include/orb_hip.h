@@ -108,7 +108,13 @@ int orb_quadtree_second_pass_levels(orb_ctx* ctx, int* levels);
 
 /* After *_device calls have completed: 0 if no internal capacity or depth
  * limit was hit by the extraction batches and windowed-matcher calls since the
- * last check, else ORB_ERR_CAPACITY (synchronises). */
+ * last check, else ORB_ERR_CAPACITY (synchronises).
+ *
+ * One context = one set of scratch buffers.  Calls on a context must not
+ * overlap: a *_device call still running on the caller's stream when another
+ * entry point of the same context starts (host-pointer ones included, which
+ * use streams of the context) would have its scratch overwritten.  Wait for
+ * the stream, or use one context per stream. */
 int orb_check_last_batch(orb_ctx* ctx);
 
 /* ORBextractor::mvImagePyramid[level] (include/ORBextractor.h:71) of frame
@@ -199,10 +205,15 @@ int orb_match_window_batch_device(orb_ctx* ctx, int npairs, const orb_keypoint* 
  * entries of 4 bytes (e.g. 64 pairs of 2070-keypoint frames: 136 MB), and one
  * candidate pool for what windows hold beyond their first 256 candidates: 4 Mi
  * entries (16 MiB) to start with, never more than the worst case.  A call whose
- * windows overrun the pool fails with ORB_ERR_CAPACITY (the asynchronous entry
- * point through orb_check_last_batch), nothing is truncated, and the pool is
- * grown to what that call needed before the next one; the host-pointer entry
- * points grow it and run again by themselves.  orb_match_reserve_candidates sets
+ * windows overrun the pool fails with ORB_ERR_CAPACITY and the pool is grown to
+ * what that call needed before the next one.  The host-pointer entry points
+ * write no output in that case, grow the pool and run again by themselves.  The
+ * asynchronous entry point cannot: it reports through orb_check_last_batch, and
+ * in every pair that held a query whose window did not fit, that query's list
+ * was cut at 256 candidates, so the pair's d_matches12 / d_prev_xy are void and
+ * its d_nmatches is -1.  The report stays pending until orb_check_last_batch
+ * collects it, whatever host-pointer calls are made on the context meanwhile
+ * (they keep error words of their own).  orb_match_reserve_candidates sets
  * the pool size (entries) ahead of time, e.g. before asynchronous calls with
  * whole-image windows: the worst case is pairs * stride1 * (stride2 - 256). */
 int orb_match_reserve_candidates(orb_ctx* ctx, long long entries);
@@ -300,7 +311,9 @@ int orb_bf_set_database(orb_bf* bf, const uint8_t* db, int64_t n, int64_t global
 /* The same from device memory; the shard keeps the pointer (no copy). */
 int orb_bf_set_database_device(orb_bf* bf, const uint8_t* d_db, int64_t n, int64_t global_base);
 
-/* Whole query on one shard, host buffers. */
+/* Whole query on one shard, host buffers.  Row numbers come back as int32_t
+ * (-1 = none): a shard whose last global row is above 2^31 - 1 is refused
+ * (ORB_ERR_UNSUPPORTED); the packed form below carries 32 bits. */
 int orb_bf_query_top2(orb_bf* bf, const uint8_t* q, int nq, int32_t* best_idx, uint16_t* best_dist,
                       uint16_t* second_dist);
 
@@ -345,7 +358,8 @@ int orb_bf_multi_create(const int* devices, int ndev, orb_bf_multi** out);
 void orb_bf_multi_destroy(orb_bf_multi* m);
 /* 1: RCCL all-gather, 0: device-to-device copies. */
 int orb_bf_multi_exchange(const orb_bf_multi* m);
-/* n x 32 bytes in host memory; block r = rows [r n / R, (r + 1) n / R), uploaded by one host thread per device. */
+/* n x 32 bytes in host memory (n <= 2^31 - 1: results are int32_t row numbers); block r = rows
+ * [r n / R, (r + 1) n / R), uploaded by one host thread per device. */
 int orb_bf_multi_set_database(orb_bf_multi* m, const uint8_t* db, int64_t n);
 int orb_bf_multi_query_top2(orb_bf_multi* m, const uint8_t* q, int nq, int32_t* best_idx, uint16_t* best_dist,
                             uint16_t* second_dist);

@@ -135,6 +135,32 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
 
 // include/ORBmatcher.h:197, declared only; upstream ORB-SLAM2: a smaller window when the point is seen
 // almost along its mean viewing direction.
+// src/ORBmatcher.cc:413-454: the three fullest bins, an earlier bin winning among equals (a bin moves up only
+// past strictly smaller ones); the second and third are dropped when they hold less than a tenth of the first.
+// As in the reference, ind1..ind3 are only written when a bin takes the place: callers pass them in as -1.
+void ORBmatcher::ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {
+    int top[3] = {0, 0, 0};
+    int* const ind[3] = {&ind1, &ind2, &ind3};
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        int place = 3;
+        while (place > 0 && s > top[place - 1]) place--;
+        if (place == 3) continue;
+        for (int k = 2; k > place; k--) {
+            top[k] = top[k - 1];
+            *ind[k] = *ind[k - 1];
+        }
+        top[place] = s;
+        *ind[place] = i;
+    }
+    if ((float)top[1] < 0.1f * (float)top[0]) {
+        ind2 = -1;
+        ind3 = -1;
+    } else if ((float)top[2] < 0.1f * (float)top[0]) {
+        ind3 = -1;
+    }
+}
+
 float ORBmatcher::RadiusByViewingCos(const float& viewCos) {
     if (viewCos > 0.998) return 2.5;
     return 4.0;

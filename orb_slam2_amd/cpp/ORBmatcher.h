@@ -71,8 +71,10 @@ protected:
                         const cv::Mat& descriptorsKF, const DBoW2::FeatureVector& vFeatVecKF, Frame& F,
                         std::vector<MapPoint*>& vpMapPointMatches);
     float RadiusByViewingCos(const float& viewCos);  // include/ORBmatcher.h:197
-    // (ComputeThreeMaxima, include/ORBmatcher.h:198, is a protected helper of the reference's host loops; here the
-    // rotation histogram and its three maxima are part of the matching kernels, so the class has no such member)
+    // include/ORBmatcher.h:198, src/ORBmatcher.cc:413-454.  The searches of this class do not call it (the rotation
+    // histogram and its three maxima are part of the matching kernels); it is kept as the host helper it is in
+    // the reference for subclasses and friends that use it.
+    void ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3);
 
     float mfNNratio;
     bool mbCheckOrientation;

@@ -579,6 +579,11 @@ extern "C" int orb_bf_query_top2(orb_bf* bf, const uint8_t* q, int nq, int32_t* 
         return ORB_ERR_INVALID;
     }
     if (nq == 0) return ORB_OK;
+    if (bf->globalBase + bf->n > 0x7FFFFFFFll) {
+        orb_set_error("orb_bf_query_top2 returns row numbers as int32_t (-1 = none): rows up to %lld do not fit; the packed entry points carry 32 bits",
+                      (long long)(bf->globalBase + bf->n - 1));
+        return ORB_ERR_UNSUPPORTED;
+    }
     HIP_TRY(hipSetDevice(bf->device));
     int rc = bf_ensure(bf->d_q, bf->qBytes, (size_t)nq * 32);
     if (!rc) rc = bf_ensure(bf->d_packed, bf->packedBytes, (size_t)nq * 8);

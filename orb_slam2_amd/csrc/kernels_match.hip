@@ -313,9 +313,12 @@ __global__ __launch_bounds__(256) void k_match_lists(const orb_keypoint* __restr
         if (lane == 0) start = atomicAdd(B.poolUsed, (unsigned)(n - B.capQ));
         start = __shfl(start, 0, 64);
         if (start + (unsigned)(n - B.capQ) > B.poolCap || start + (unsigned)(n - B.capQ) < start) {
-            // nothing is truncated silently: the call reports ORB_ERR_CAPACITY and what it would have needed
+            // The list is cut at capQ entries, and never silently: the error word makes the call report
+            // ORB_ERR_CAPACITY with what it would have needed, and the query's pool offset -1 makes the resolve
+            // kernel give the pair a match count of -1.
             if (lane == 0) atomicOr(error, M_ERR_POOL);
             n = B.capQ;
+            ovf = -1;
             break;
         }
         ovf = (int)start;
@@ -399,6 +402,7 @@ struct ResolveLds {
     int hist[ORB_HISTO + 1];  // entry ORB_HISTO: rotations rot_bin could not place
     int wcount[4];
     int nmatches;
+    int cut;  // some query's candidate list was cut short (pool overrun): the pair's results are void
 };
 
 template <int MODE>
@@ -451,7 +455,10 @@ __global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __res
         else S.so[p] = 0xFFFFFFFFu;                                            // distance INT_MAX, owner -1
     }
     if (t <= ORB_HISTO) S.hist[t] = 0;
-    if (t == 0) S.nmatches = 0;
+    if (t == 0) {
+        S.nmatches = 0;
+        S.cut = 0;
+    }
     __syncthreads();
 
     // Queries with a non-empty list, in index order (the others cannot match and change nothing).
@@ -461,6 +468,7 @@ __global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __res
     for (int b0 = 0; b0 < nq; b0 += 256) {
         const int i = b0 + t;
         const bool act = i < nq && counts[i] > 0;
+        if (act && B.ovfStart[(int64_t)pair * stride1 + i] < 0) S.cut = 1;  // (benign race: every writer stores 1)
         const unsigned long long m = __ballot(act);
         if (lane == 0) S.wcount[wave] = __popcll(m);
         __syncthreads();
@@ -649,11 +657,14 @@ __global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __res
             }
         }
     }
-    if (t == 0) nmatchesOut[pair] = nmatches;
+    if (t == 0) nmatchesOut[pair] = S.cut ? -1 : nmatches;
 }
 
 // ---- host side ------------------------------------------------------------------------
 struct MatchState {
+    // Two pairs of error words (flags, pool entries asked for): [0..1] for the asynchronous entry point, read by
+    // orb_check_last_batch; [2..3] for the host-pointer entry points, which read and clear theirs before they
+    // return.  A pending asynchronous report thus survives any synchronous call made before it is collected.
     void* err = nullptr;
     // scratch, grown on demand and kept
     void* gSorted = nullptr; void* gXY = nullptr; void* gOct = nullptr; void* cellStart = nullptr;
@@ -707,12 +718,13 @@ static int grow(void** p, size_t bytes) {
 #define M_POOL_DEFAULT ((size_t)4 << 20)   // pool entries (16 MiB) a context starts with
 
 // Makes the scratch large enough for npairs pairs of (stride1 queries, stride2 searched keypoints).
-static int match_buffers(orb_ctx* c, int npairs, int stride1, int stride2, MatchState** out, MatchBuffers* B) {
+static int match_buffers(orb_ctx* c, int npairs, int stride1, int stride2, MatchState** out, MatchBuffers* B,
+                         bool sync = true, int** errw = nullptr) {
     void** slot = orb_ctx_match_state(c);
     if (!*slot) {
         MatchState* s = new MatchState();
-        hipError_t e = hipMalloc(&s->err, 8);  // flags, pool entries asked for
-        if (e == hipSuccess) e = hipMemset(s->err, 0, 8);
+        hipError_t e = hipMalloc(&s->err, 16);
+        if (e == hipSuccess) e = hipMemset(s->err, 0, 16);
         if (e != hipSuccess) {
             delete s;
             orb_set_error("matcher state allocation failed: %s", hipGetErrorString(e));
@@ -777,7 +789,9 @@ static int match_buffers(orb_ctx* c, int npairs, int stride1, int stride2, Match
     B->pool = (uint32_t*)s->pool;
     B->ovfStart = (int*)s->ovfStart;
     B->poolCap = (unsigned)s->poolCap;
-    B->poolUsed = (unsigned*)s->err + 1;
+    int* const words = (int*)s->err + (sync ? 2 : 0);
+    B->poolUsed = (unsigned*)words + 1;
+    if (errw) *errw = words;
     *out = s;
     return ORB_OK;
 }
@@ -813,11 +827,11 @@ static int check_match_launch() {
     return ORB_OK;
 }
 
-extern "C" int orb_match_window_batch_device(orb_ctx* c, int npairs, const orb_keypoint* d_k1, const uint8_t* d_d1,
-                                             const int* d_n1, int stride1, const orb_keypoint* d_k2,
-                                             const uint8_t* d_d2, const int* d_n2, int stride2, int img_w, int img_h,
-                                             float* d_prev_xy, int* d_matches12, int window, float nnratio,
-                                             int check_ori, int* d_nmatches, void* stream) {
+static int match_window_batch(orb_ctx* c, int npairs, const orb_keypoint* d_k1, const uint8_t* d_d1,
+                              const int* d_n1, int stride1, const orb_keypoint* d_k2,
+                              const uint8_t* d_d2, const int* d_n2, int stride2, int img_w, int img_h,
+                              float* d_prev_xy, int* d_matches12, int window, float nnratio,
+                              int check_ori, int* d_nmatches, void* stream, bool sync) {
     if (!c || npairs < 1 || !d_k1 || !d_d1 || !d_n1 || !d_k2 || !d_d2 || !d_n2 || !d_prev_xy || !d_matches12 ||
         !d_nmatches || stride1 < 1 || stride2 < 1 || img_w < 1 || img_h < 1) {
         orb_set_error("orb_match_window_batch_device: bad arguments");
@@ -835,24 +849,34 @@ extern "C" int orb_match_window_batch_device(orb_ctx* c, int npairs, const orb_k
     HIP_TRY(hipSetDevice(orb_ctx_device(c)));
     MatchState* s = nullptr;
     MatchBuffers B;
-    int rc = match_buffers(c, npairs, stride1, stride2, &s, &B);
+    int* errw = nullptr;
+    int rc = match_buffers(c, npairs, stride1, stride2, &s, &B, sync, &errw);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const GridGeom G = grid_geom(c, img_w, img_h);
     hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(256), 0, st, d_k2, d_n2, 0, stride2, G, B,
-                       (int*)s->err);
+                       errw);
     if ((rc = check_match_launch())) return rc;
     HIP_TRY(hipMemsetAsync(B.poolUsed, 0, 4, st));
     hipLaunchKernelGGL(k_match_lists<false>, dim3((stride1 + 3) / 4, npairs), dim3(256), 0, st, d_k1, d_d1, d_n1, 0,
                        stride1, (const float*)d_prev_xy, (float)window, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const int*)nullptr, (const int*)nullptr, d_d2, stride2, G, orb_ctx_quirks(c), B,
-                       (int*)s->err);
+                       errw);
     if ((rc = check_match_launch())) return rc;
     hipLaunchKernelGGL(k_match_resolve<0>, dim3(npairs), dim3(256), 0, st, d_k1, d_n1, 0, stride1, d_k2, d_n2, 0,
                        stride2, d_prev_xy, d_matches12, (uint8_t*)s->binOf, (const float*)nullptr,
                        (const uint8_t*)nullptr, (const uint8_t*)nullptr, (int*)nullptr, nnratio, 0, check_ori, B,
-                       d_nmatches, (int*)s->err);
+                       d_nmatches, errw);
     return check_match_launch();
+}
+
+extern "C" int orb_match_window_batch_device(orb_ctx* c, int npairs, const orb_keypoint* d_k1, const uint8_t* d_d1,
+                                             const int* d_n1, int stride1, const orb_keypoint* d_k2,
+                                             const uint8_t* d_d2, const int* d_n2, int stride2, int img_w, int img_h,
+                                             float* d_prev_xy, int* d_matches12, int window, float nnratio,
+                                             int check_ori, int* d_nmatches, void* stream) {
+    return match_window_batch(c, npairs, d_k1, d_d1, d_n1, stride1, d_k2, d_d2, d_n2, stride2, img_w, img_h, d_prev_xy,
+                              d_matches12, window, nnratio, check_ori, d_nmatches, stream, false);
 }
 
 // Host-pointer entry points: every input and output of a call is laid out in one block that exists
@@ -890,9 +914,9 @@ static int ensure_block(MatchState* s, size_t bytes) {
 // Error words of the last call as the host read them (flag[0] bits, flag[1] pool entries asked for).
 // M_RETRY: the candidate pool ran out and has been marked for growth; the caller runs the call again.
 #define M_RETRY 1
-static int match_error(const int* flag, MatchState* s, const char* what, bool mayRetry) {
+static int match_error(const int* flag, MatchState* s, const char* what, bool mayRetry, bool sync = true) {
     if (flag[0]) {
-        HIP_TRY(hipMemset(s->err, 0, 4));
+        HIP_TRY(hipMemset((int*)s->err + (sync ? 2 : 0), 0, 4));
         if (flag[0] & M_ERR_LIMIT) {
             orb_set_error("%s: keypoint count exceeds the kernel's limits", what);
             return ORB_ERR_CAPACITY;
@@ -914,7 +938,7 @@ int orb_match_check_error(orb_ctx* c) {
     if (!s) return ORB_OK;
     int flag[2] = {0, 0};
     HIP_TRY(hipMemcpy(flag, s->err, 8, hipMemcpyDeviceToHost));
-    return match_error(flag, s, "windowed matcher", false);
+    return match_error(flag, s, "windowed matcher", false, false);
 }
 
 extern "C" int orb_match_reserve_candidates(orb_ctx* c, long long entries) {
@@ -965,12 +989,11 @@ static int match_window_once(orb_ctx* c, const orb_keypoint* k1, const uint8_t* 
     memcpy(h + oN, ns, 8);
     memcpy(h + oPrev, prev_xy, (size_t)n1 * 8);
     HIP_TRY(hipMemcpyAsync(d, h, oM, hipMemcpyHostToDevice, nullptr));
-    rc = orb_match_window_batch_device(c, 1, (const orb_keypoint*)(d + oK1), d + oD1, (const int*)(d + oN), s1,
-                                       (const orb_keypoint*)(d + oK2), d + oD2, (const int*)(d + oN) + 1, s2, img_w, img_h,
-                                       (float*)(d + oPrev), (int*)(d + oM), window, nnratio, check_ori, (int*)(d + oNm),
-                                       nullptr);
+    rc = match_window_batch(c, 1, (const orb_keypoint*)(d + oK1), d + oD1, (const int*)(d + oN), s1,
+                            (const orb_keypoint*)(d + oK2), d + oD2, (const int*)(d + oN) + 1, s2, img_w, img_h,
+                            (float*)(d + oPrev), (int*)(d + oM), window, nnratio, check_ori, (int*)(d + oNm), nullptr, true);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(d + oErr, s->err, 8, hipMemcpyDeviceToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(d + oErr, (int*)s->err + 2, 8, hipMemcpyDeviceToDevice, nullptr));
     HIP_TRY(hipMemcpyAsync(h + oPrev, d + oPrev, L.off - oPrev, hipMemcpyDeviceToHost, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
     if ((rc = match_error((const int*)(h + oErr), s, "windowed matcher", mayRetry))) return rc;
@@ -1044,22 +1067,22 @@ static int match_projected_once(orb_ctx* c, int mode, const float* u, const floa
     HIP_TRY(hipMemcpyAsync(d, h, oM, hipMemcpyHostToDevice, st));
     const GridGeom G = grid_geom(c, img_w, img_h);
     hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, st, (const orb_keypoint*)(d + oK2), (const int*)nullptr, n2, n2,
-                       G, B, (int*)s->err);
+                       G, B, (int*)s->err + 2);
     if ((rc = check_match_launch())) return rc;
     HIP_TRY(hipMemsetAsync(B.poolUsed, 0, 4, st));
     hipLaunchKernelGGL(k_match_lists<true>, dim3((nq + 3) / 4, 1), dim3(256), 0, st, (const orb_keypoint*)nullptr,
                        (const uint8_t*)(d + oQ), (const int*)nullptr, nq, nq, (const float*)nullptr, 0.f,
                        (const float*)(d + oU), (const float*)(d + oV), (const float*)(d + oR), (const int*)(d + oL0),
-                       (const int*)(d + oL1), (const uint8_t*)(d + oD2), n2, G, orb_ctx_quirks(c), B, (int*)s->err);
+                       (const int*)(d + oL1), (const uint8_t*)(d + oD2), n2, G, orb_ctx_quirks(c), B, (int*)s->err + 2);
     if ((rc = check_match_launch())) return rc;
     hipLaunchKernelGGL(mode == 2 ? k_match_resolve<2> : k_match_resolve<1>, dim3(1), dim3(256), 0, st,
                        (const orb_keypoint*)nullptr, (const int*)nullptr, nq, nq, (const orb_keypoint*)(d + oK2),
                        (const int*)nullptr, n2, n2, (float*)nullptr, (int*)nullptr, (uint8_t*)s->binOf,
                        (const float*)(d + oA), qobs ? (const uint8_t*)(d + oObs) : (const uint8_t*)nullptr,
                        occupied2 ? (const uint8_t*)(d + oOcc) : (const uint8_t*)nullptr, (int*)(d + oM), nnratio, th_high,
-                       check_ori, B, (int*)(d + oNm), (int*)s->err);
+                       check_ori, B, (int*)(d + oNm), (int*)s->err + 2);
     if ((rc = check_match_launch())) return rc;
-    HIP_TRY(hipMemcpyAsync(d + oErr, s->err, 8, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + oErr, (int*)s->err + 2, 8, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(h + oM, d + oM, L.off - oM, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if ((rc = match_error((const int*)(h + oErr), s, "projected matcher", mayRetry))) return rc;
@@ -1152,14 +1175,14 @@ extern "C" int orb_match_best(orb_ctx* c, const float* u, const float* v, const 
     HIP_TRY(hipMemcpyAsync(d, h, oIdx, hipMemcpyHostToDevice, st));
     const GridGeom G = grid_geom(c, img_w, img_h);
     hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, st, (const orb_keypoint*)(d + oK2), (const int*)nullptr, n2, n2,
-                       G, B, (int*)s->err);
+                       G, B, (int*)s->err + 2);
     if ((rc = check_match_launch())) return rc;
     hipLaunchKernelGGL(k_match_best, dim3((nq + 3) / 4), dim3(256), 0, st, (const float*)(d + oU), (const float*)(d + oV),
                        (const float*)(d + oR), (const int*)(d + oL0), (const int*)(d + oL1), (const uint8_t*)(d + oQ), nq,
                        (const uint8_t*)(d + oD2), ns ? (const float*)(d + oSig) : (const float*)nullptr, ns, chi2_max, th, G,
                        orb_ctx_quirks(c), B, (int*)(d + oIdx), (int*)(d + oDist));
     if ((rc = check_match_launch())) return rc;
-    HIP_TRY(hipMemcpyAsync(d + oErr, s->err, 8, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + oErr, (int*)s->err + 2, 8, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(h + oIdx, d + oIdx, L.off - oIdx, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if ((rc = match_error((const int*)(h + oErr), s, "orb_match_best", false))) return rc;

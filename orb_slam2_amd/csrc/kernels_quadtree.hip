@@ -15,6 +15,7 @@
 // the cell), sorted by quadtree path in global memory, and distributed by
 // binary searches over the sorted array.  Same result by construction (both
 // forms are checked against the oracle's std::list restatement, tests/emu).
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -385,15 +386,19 @@ static int qt_launch(const OrbBatch& b, bool bigFrames, int pass) {
         orb_set_error("internal: quadtree LDS block of %zu bytes", lds);
         return ORB_ERR_UNSUPPORTED;
     }
-    if (lds > 64 * 1024) {  // more dynamic LDS than the default per-workgroup limit: ask for it (once per process is enough)
-        static bool asked = false;
-        if (!asked) {
+    if (lds > 64 * 1024) {
+        // More dynamic LDS than the default per-workgroup limit: ask for it, once per device (the attribute belongs
+        // to the device's copy of the kernel; contexts of several devices run on several host threads).
+        static std::atomic<bool> asked[64];
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !asked[dev].load(std::memory_order_acquire)) {
             hipError_t ea = hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - QT_STATIC_LDS);
             if (ea != hipSuccess) {
                 orb_set_error("quadtree: %zu bytes of LDS per workgroup refused: %s", lds, hipGetErrorString(ea));
                 return ORB_ERR_HIP;
             }
-            asked = true;
+            if (dev >= 0 && dev < 64) asked[dev].store(true, std::memory_order_release);
         }
     }
     // every frame group of a batch has its own list (a count, then at most one entry per (frame, level))

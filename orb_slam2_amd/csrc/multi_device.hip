@@ -174,8 +174,8 @@ extern "C" int orb_bf_multi_create(const int* devices, int ndev, orb_bf_multi** 
 extern "C" int orb_bf_multi_exchange(const orb_bf_multi* m) { return m ? (m->useRccl ? 1 : 0) : -1; }
 
 extern "C" int orb_bf_multi_set_database(orb_bf_multi* m, const uint8_t* db, int64_t n) {
-    if (!m || n < 0 || (n > 0 && !db) || n > 0xFFFFFFFFll) {
-        orb_set_error("orb_bf_multi_set_database: bad arguments (rows are indexed with 32 bits)");
+    if (!m || n < 0 || (n > 0 && !db) || n > 0x7FFFFFFFll) {
+        orb_set_error("orb_bf_multi_set_database: bad arguments (row numbers come back as int32_t, -1 = none: at most 2^31 - 1 rows)");
         return ORB_ERR_INVALID;
     }
     // contiguous row blocks [r n / R, (r + 1) n / R), uploaded by one host thread per device
@@ -224,15 +224,9 @@ static int multi_ensure(orb_bf_multi* m, int nq) {
     return ORB_OK;
 }
 
-extern "C" int orb_bf_multi_query_top2(orb_bf_multi* m, const uint8_t* q, int nq, int32_t* best_idx, uint16_t* best_dist,
-                                       uint16_t* second_dist) {
-    if (!m || nq < 0 || (nq > 0 && !q)) {
-        orb_set_error("orb_bf_multi_query_top2: bad arguments");
-        return ORB_ERR_INVALID;
-    }
-    if (nq == 0) return ORB_OK;
-    int rc = multi_ensure(m, nq);
-    if (rc) return rc;
+// Everything orb_bf_multi_query_top2 puts on the devices' streams; the caller waits for them whatever this returns.
+static int multi_enqueue(orb_bf_multi* m, const uint8_t* q, int nq) {
+    int rc;
     const int R = m->ndev;
     uint8_t* pin = (uint8_t*)m->pin;
     memcpy(pin, q, (size_t)nq * 32);
@@ -247,9 +241,16 @@ extern "C" int orb_bf_multi_query_top2(orb_bf_multi* m, const uint8_t* q, int nq
     // the one exchange step: every device receives every shard's packed words, shard s at [s * nq, (s + 1) * nq)
     if (m->useRccl) {
         NCCL_TRY(m, m->rccl->GroupStart());
-        for (int r = 0; r < R; r++)
-            NCCL_TRY(m, m->rccl->AllGather(m->dPacked[r], m->dGath[r], (size_t)nq, ncclUint64, m->comm[r], m->stream[r]));
-        NCCL_TRY(m, m->rccl->GroupEnd());
+        ncclResult_t bad = ncclSuccess;
+        for (int r = 0; r < R && bad == ncclSuccess; r++)
+            bad = m->rccl->AllGather(m->dPacked[r], m->dGath[r], (size_t)nq, ncclUint64, m->comm[r], m->stream[r]);
+        // the group is closed whatever happened inside it: an open group would swallow every later RCCL call of the process
+        const ncclResult_t end = m->rccl->GroupEnd();
+        if (bad != ncclSuccess || end != ncclSuccess) {
+            orb_set_error("ncclAllGather of %d packed words over %d devices failed: %s", nq, R,
+                          m->rccl->GetErrorString(bad != ncclSuccess ? bad : end));
+            return ORB_ERR_HIP;
+        }
     } else {
         for (int r = 0; r < R; r++) {
             HIP_TRY(hipSetDevice(m->dev[r]));
@@ -270,11 +271,31 @@ extern "C" int orb_bf_multi_query_top2(orb_bf_multi* m, const uint8_t* q, int nq
     }
     HIP_TRY(hipSetDevice(m->dev[0]));
     HIP_TRY(hipMemcpyAsync(pin + (size_t)nq * 32, m->dOut[0], (size_t)nq * 8, hipMemcpyDeviceToHost, m->stream[0]));
-    for (int r = R - 1; r >= 0; r--) {
-        HIP_TRY(hipSetDevice(m->dev[r]));
-        HIP_TRY(hipStreamSynchronize(m->stream[r]));
+    return ORB_OK;
+}
+
+extern "C" int orb_bf_multi_query_top2(orb_bf_multi* m, const uint8_t* q, int nq, int32_t* best_idx, uint16_t* best_dist,
+                                       uint16_t* second_dist) {
+    if (!m || nq < 0 || (nq > 0 && !q)) {
+        orb_set_error("orb_bf_multi_query_top2: bad arguments");
+        return ORB_ERR_INVALID;
     }
-    const uint8_t* o = pin + (size_t)nq * 32;
+    if (nq == 0) return ORB_OK;
+    int rc = multi_ensure(m, nq);
+    if (rc) return rc;
+    rc = multi_enqueue(m, q, nq);
+    // Success or not, nothing of this call may still be running when it returns: the streams read the page-locked
+    // block and write the gather buffers, which the next call overwrites.
+    for (int r = m->ndev - 1; r >= 0; r--) {
+        hipError_t e = hipSetDevice(m->dev[r]);
+        if (e == hipSuccess) e = hipStreamSynchronize(m->stream[r]);
+        if (e != hipSuccess && rc == ORB_OK) {
+            orb_set_error("orb_bf_multi_query_top2: device %d: %s", m->dev[r], hipGetErrorString(e));
+            rc = ORB_ERR_HIP;
+        }
+    }
+    if (rc) return rc;
+    const uint8_t* o = (const uint8_t*)m->pin + (size_t)nq * 32;
     if (best_idx) memcpy(best_idx, o, (size_t)nq * 4);
     if (best_dist) memcpy(best_dist, o + (size_t)nq * 4, (size_t)nq * 2);
     if (second_dist) memcpy(second_dist, o + (size_t)nq * 6, (size_t)nq * 2);

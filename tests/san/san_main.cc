@@ -190,6 +190,24 @@ int main() {
         CHECK(Ow.at<float>(0, 0) == -1.f && Ow.at<float>(1, 0) == 2.f && Ow.at<float>(2, 0) == -0.5f && Rwc.at<float>(1, 1) == 1.f);
         Frame G(F);  // copy constructor: pose matrices follow
         CHECK(G.GetCameraCenter().at<float>(1, 0) == 2.f);
+        // the protected host helper the reference's subclasses may use, against the oracle's restatement
+        struct Open : ORBmatcher {
+            using ORBmatcher::ComputeThreeMaxima;
+        } om;
+        unsigned rs = 12345u;
+        for (int rep = 0; rep < 2000; rep++) {
+            std::vector<int> histo[30];
+            int counts[30];
+            for (int i = 0; i < 30; i++) {
+                rs = rs * 1664525u + 1013904223u;
+                counts[i] = (rep % 3 == 0) ? (int)((rs >> 24) % 4) : (int)((rs >> 20) % 50) * (int)((rs >> 12) % 2);
+                histo[i].assign((size_t)counts[i], 0);
+            }
+            int a1 = -1, a2 = -1, a3 = -1, b1 = -1, b2 = -1, b3 = -1;
+            om.ComputeThreeMaxima(histo, 30, a1, a2, a3);
+            computeThreeMaxima(counts, 30, b1, b2, b3);
+            CHECK(a1 == b1 && a2 == b2 && a3 == b3);
+        }
     }
     printf("sanitizer driver: ok (%zu + %zu keypoints)\n", k1.size(), k2.size());
     return 0;

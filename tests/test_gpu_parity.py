@@ -466,6 +466,16 @@ def test_matcher_wide_windows_use_the_candidate_pool(hip, oracle):
             d_nm = torch.zeros(1, dtype=torch.int32, device="cuda")
             d_prev = t(prev[None])
             c2.match_window_batch_device(d_k1, d_d1, d_n1, d_k2, d_d2, d_n2, w, h, d_prev, d_m12, d_nm, window, 0.9, True)
+            # ... the pair whose lists were cut carries a match count of -1, and a host-pointer call made on the
+            # context before the report is collected neither takes the report for its own nor loses it
+            torch.cuda.synchronize()
+            assert int(d_nm.item()) == -1
+            ks, ds = k1[:300].copy(), d1[:300].copy()
+            ps = prev[:300].copy()
+            ns, ms, _ = c2.match_window(ks, ds, k2, d2, w, h, ps, 150, 0.9, True)
+            nso, mso, _ = oracle.search_for_initialization(ks, ds, k2, d2, w, h, ps, 150, 0.9, True, PRESETS["fork"])
+            assert ns == nso
+            np.testing.assert_array_equal(ms, mso)
             with pytest.raises(hip.OrbError, match="candidate pool"):
                 c2.check_last_batch()
             # ... the next one runs with the pool that call asked for
