@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=300, help="frames the single-thread CPU baseline extracts (about 10 s)")
     ap.add_argument("--no-extras", action="store_true", help="skip batch sweep, host path, single frame and other configurations")
+    ap.add_argument("--job-frames", type=int, default=1024, help="frames of the 3840x2160 job (configuration 4), over ALL ranks")
     args = ap.parse_args()
 
     # The one JSON line is all this program writes to its standard output: whatever libraries print there meanwhile
@@ -124,6 +125,21 @@ def main():
         t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    def sum_over_ranks(x):
+        if not grouped:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearse else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t.item())
+
+    # a host-side group next to the RCCL one: ranks that only wait (while rank 0 runs a program of its own over
+    # all GPUs) must not wait inside a collective kernel that spins on their GPU
+    host_group = dist.new_group(backend="gloo") if grouped and not rehearse else None
+
+    def host_barrier():
+        if grouped:
+            dist.barrier(group=host_group) if host_group is not None else dist.barrier()
 
     def note(what):
         if rehearse:
@@ -265,6 +281,7 @@ def main():
         sbf.query(d_q)
         torch.cuda.synchronize()
         note("first brute-force step done")
+        bf.clock_probe(True)  # (clears the sums: the timed scans below are what the probe sees)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.bf_steps):
@@ -273,6 +290,7 @@ def main():
             kern_ms.append(ev0.elapsed_time(ev1))
         barrier()
         dth = max_over_ranks(time.perf_counter() - t0)
+        clock_mhz = bf.clock_probe(False)  # shader-clock ticks per tick of the 100 MHz counter, over the timed scans' workgroups
         gcmp = nq * nd * args.bf_steps / dth / 1e9
         kms = float(np.mean(kern_ms))
         kern_gcmp = nq * (hi - lo) / (kms * 1e-3) / 1e9
@@ -290,6 +308,10 @@ def main():
                                              "gcmp_per_s": 2734, "ceiling_gcmp_per_s": round(VALU_LANE_OPS / 16 / 1e9),
                                              "this_kernel_over_its_ceiling": round(lane_ops / VALU_LANE_OPS, 3)},
                          "launch_ms": round(kms, 3),
+                         # the same against what the matrix cores could do at the clock the launch actually ran at
+                         # (the board lowers it under this kernel's power draw): 4096 operations per cycle and SIMD
+                         "clock_mhz": round(clock_mhz, 1),
+                         "frac_at_clock": round(kern_gcmp * 1e9 * 512 / (1024 * clock_mhz * 1e6 * 4096), 4) if clock_mhz > 0 else None,
                          "db_stream_GBs": round((hi - lo) * 32 * ((nq + 511) // 512) / (kms * 1e-3) / 1e9, 1)},
         }
         if rank == 0 and not args.no_cpu:
@@ -452,8 +474,38 @@ def main():
                 except Exception as ex:  # the demo is an extra, never a reason to lose the benchmark line
                     single_ms["orb_demo_error"] = str(ex)[-200:]
         extras["single_frame_ms"] = single_ms
-        # the other configurations make contexts of their own; this one's streams would compete with theirs for the
-        # process's few hardware queues
+        # the other preset (every switch of the fork's deviations flipped: INTER_LINEAR pyramid, canonical umax, ...),
+        # same frames, same step
+        other_preset = "canonical" if args.preset == "fork" else "fork"
+        oq = binding.ORB_QUIRKS_CANONICAL if other_preset == "canonical" else binding.ORB_QUIRKS_FORK
+        ctx2 = binding.Context(args.nfeatures, 1.2, 8, 20, 7, W, H, B, local, oq)
+        k2 = [0]
+
+        def step2():
+            ctx2.extract_batch_device(d_batches[k2[0] % 3], d_kps, d_desc, d_cnt, stream)
+            k2[0] += 1
+
+        t = wall(step2, args.steps, warm=args.warmup)
+        ctx2.check_last_batch()
+        k2[0] = 0
+        step2()
+        torch.cuda.synchronize()
+        c2 = d_cnt.cpu().numpy()
+        e2 = oracle.Extractor(args.nfeatures, 1.2, 8, 20, 7, oracle.QUIRKS_CANONICAL if other_preset == "canonical" else oracle.QUIRKS_FORK)
+        ko2, do2 = e2.extract(frames[0])
+        kg2 = d_kps[0, : c2[0]].cpu().numpy().view(binding.KP_DTYPE).reshape(-1)
+        extras["other_preset"] = {"preset": other_preset, "frames_per_s": round(B / t, 1), "ms_per_step": round(t * 1e3, 4),
+                                  "steps": args.steps, "keypoints_per_frame": round(float(c2.mean()), 1),
+                                  "parity_checked": bool(len(kg2) == len(ko2) and (kg2 == ko2).all() and
+                                                         (d_desc[0, : c2[0]].cpu().numpy() == do2).all())}
+        ctx2.close()
+
+    # ---- the other configurations, on one GPU or sharded over the ranks ---------------------------------------
+    # (they make contexts of their own; this one's streams would compete with theirs for the process's few hardware
+    # queues)
+    other = None
+    if not args.no_extras:
+        host_barrier()  # (rank 0 has been busy with the CPU baseline: the others wait for it on the host, not in a collective kernel)
         ctx.close()
         if not args.no_hamming:
             bf.close()
@@ -461,9 +513,40 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_configs
 
-            extras["other_configs"] = [bench_configs.config2(), bench_configs.config3(), bench_configs.config4()]
+            R = bench_configs.Ranks(rank, world, local, barrier, max_over_ranks, sum_over_ranks)
+            note("configuration 2")
+            other = [bench_configs.config2(R)]
+            if world == 1:
+                other.append(bench_configs.config3(R))  # pairs are independent: more GPUs would be replicas
+            note("configuration 4")
+            other.append(bench_configs.config4(R, job=args.job_frames))
         except Exception as ex:
-            extras["other_configs"] = {"error": str(ex)[-300:]}
+            if grouped:
+                raise  # the ranks must stay in step: a rank that drops out would leave the others in a collective
+            other = {"error": str(ex)[-300:]}
+        if extras is None and rank == 0:
+            extras = {}
+        if rank == 0:
+            extras["other_configs"] = other
+
+    # ---- every visible GPU from ONE process, plain C++ (orb_bf_multi_*: RCCL all-gather inside the library) --------
+    # rank 0 runs the example over as many devices as there are ranks (all visible ones in a single-rank run);
+    # the other ranks wait on the host
+    if not args.no_extras and not args.no_hamming and not rehearse:
+        ndev = torch.cuda.device_count()
+        use = min(ndev, world) if world > 1 else 1
+        exe = os.path.join(ROOT, "examples", "orb_bf_multi")
+        if rank == 0 and use > 1 and os.path.exists(exe):
+            import subprocess
+
+            try:
+                r = subprocess.run([exe, ",".join(str(d) for d in range(use)), "4000000", "20000"], capture_output=True,
+                                   text=True, timeout=240)
+                extras["one_process_all_gpus"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else \
+                    {"error": (r.stderr or r.stdout)[-300:]}
+            except Exception as ex:
+                extras["one_process_all_gpus"] = {"error": str(ex)[-300:]}
+        host_barrier()
 
     if rank == 0:
         out = {

@@ -335,6 +335,14 @@ int orb_bf_query_packed_device(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t*
 #define ORB_BF_NOALLOC_MAX_QUERIES 262144
 int orb_bf_query_packed_noalloc(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t* d_packed, void* stream);
 
+/* Measurement aid (no counterpart in the reference): the engine clock the scan
+ * kernel ran at.  enable != 0 makes the following scans of this shard add up
+ * shader-clock ticks and ticks of the constant 100 MHz counter over their
+ * workgroups; every call waits for the device, returns through *mhz (may be
+ * NULL) the ratio seen since the previous call (0 if nothing ran) and clears the
+ * sums.  enable == 0 switches the probe off again. */
+int orb_bf_clock_probe(orb_bf* bf, int enable, double* mhz);
+
 /* Merge nshards packed results per query (d_gathered[s*nq + i], the layout an
  * all-gather produces) into the final answer; equals a scan of the whole
  * database.  Device buffers, asynchronous. */

@@ -30,7 +30,7 @@ EXPORTS = [
     "orb_compute_tables",
     "orb_debug_get_fast_keys", "orb_resize", "orb_gaussian_blur", "orb_hamming", "orb_match_window",
     "orb_match_window_batch_device", "orb_match_reserve_candidates", "orb_match_projected", "orb_bf_create", "orb_bf_destroy", "orb_bf_set_database",
-    "orb_bf_set_database_device", "orb_bf_query_top2", "orb_bf_query_packed_device", "orb_bf_query_packed_noalloc", "orb_bf_merge_packed_device",
+    "orb_bf_set_database_device", "orb_bf_query_top2", "orb_bf_query_packed_device", "orb_bf_query_packed_noalloc", "orb_bf_clock_probe", "orb_bf_merge_packed_device",
     "orb_bf_multi_create", "orb_bf_multi_destroy", "orb_bf_multi_exchange", "orb_bf_multi_set_database",
     "orb_bf_multi_query_top2", "orb_extract_batch_multi",
     "orb_enable_stage_timing", "orb_get_stage_timings", "orb_last_error", "orb_version",
@@ -440,6 +440,13 @@ class BruteForce:
     def query_packed_noalloc(self, d_q, d_packed, stream=None):
         """The same through the entry point that allocates nothing (fixed partials block in the library)."""
         _check(lib().orb_bf_query_packed_noalloc(self.h, _dp(d_q), d_q.shape[0], _dp(d_packed), _stream(stream)))
+
+    def clock_probe(self, enable=True):
+        """Engine clock (MHz) the scans since the previous call ran at (0.0 if none ran with the probe on); switches
+        the probe on or off for the scans that follow.  Waits for the device."""
+        mhz = C.c_double(0.0)
+        _check(lib().orb_bf_clock_probe(self.h, int(enable), C.byref(mhz)))
+        return mhz.value
 
 
 class MultiBruteForce:

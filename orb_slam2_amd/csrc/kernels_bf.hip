@@ -35,6 +35,7 @@ struct orb_bf {
     hipStream_t stream = nullptr;
     int residentBlocks = 0;  // workgroups of the scan kernel the device holds at once
     unsigned long long* d_static = nullptr;  // this device's copy of the library-held partials block (see below)
+    unsigned long long* d_clock = nullptr;   // engine-clock probe (orb_bf_clock_probe): two sums the scan kernel adds to
 };
 
 // Per-chunk partial results for orb_bf_query_packed_noalloc, the entry point for callers that must not
@@ -133,7 +134,8 @@ static __device__ __forceinline__ bfm_v4i bfm_expand32(uint32_t bits) {
 __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__ q, int nq, const uint32_t* __restrict__ db,
                                                     long long n, long long rowsPerChunk, long long globalBase,
                                                     unsigned long long* __restrict__ partial,
-                                                    uint32_t* __restrict__ shared) {  // (null: a single chunk)
+                                                    uint32_t* __restrict__ shared,  // (null: a single chunk)
+                                                    unsigned long long* __restrict__ clk) {  // (null: no clock probe)
     static_assert(BFM_QB == 4 && BFM_TR == 64, "the interleaving is written for four query blocks and two row blocks");
     extern __shared__ __attribute__((aligned(16))) uint8_t s_rows[];  // two buffers of BFM_TR expanded rows
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, h = lane >> 5, c = lane & 31;
@@ -142,6 +144,9 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__
     const long long rEnd = r0 + rowsPerChunk < n ? r0 + rowsPerChunk : n;
     const int rows = (int)(rEnd - r0);
     if (rows <= 0) return;  // (the whole workgroup; the launcher makes no such chunk)
+    // engine clock while the launch runs: shader-clock ticks per tick of the constant 100 MHz counter, summed over
+    // the workgroups (each weighs in with its own duration)
+    const unsigned long long clk0 = clk ? clock64() : 0ull, wall0 = clk ? wall_clock64() : 0ull;
 
     bfm_v4i bq[BFM_QB][4];
     int pcq[BFM_QB];  // popcount of the lane's queries: distance = popcount - product
@@ -309,6 +314,10 @@ __global__ __launch_bounds__(256, 2) void k_bf_mfma(const uint32_t* __restrict__
             partial[((long long)blockIdx.y * 2 + h) * nq + qi] = (bd << 48) | (sd << 32) | idx;
         }
     }
+    if (clk && t == 0) {
+        atomicAdd(&clk[0], clock64() - clk0);
+        atomicAdd(&clk[1], wall_clock64() - wall0);
+    }
 }
 #define BF_PARTS_PER_CHUNK 2  // partial words per (chunk, query): one per half of the wavefront
 
@@ -392,6 +401,7 @@ extern "C" void orb_bf_destroy(orb_bf* bf) {
     bf_free(bf->d_q);
     bf_free(bf->d_packed);
     bf_free(bf->d_out);
+    if (bf->d_clock) (void)hipFree(bf->d_clock);
     if (bf->stream) (void)hipStreamDestroy(bf->stream);
     delete bf;
 }
@@ -501,7 +511,7 @@ static int bf_scan_into(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t* d_pack
         uint32_t* shared = chunks > 1 ? (uint32_t*)scratch : nullptr;
         if (shared) HIP_TRY(hipMemsetAsync(shared, 0, bf_threshold_words(nq) * 8, st));
         hipLaunchKernelGGL(k_bf_mfma, dim3(qBlocks, chunks), dim3(256), BFM_LDS, st, (const uint32_t*)d_q, nq,
-                           (const uint32_t*)bf->d_db, (long long)bf->n, rpc, (long long)bf->globalBase, partial, shared);
+                           (const uint32_t*)bf->d_db, (long long)bf->n, rpc, (long long)bf->globalBase, partial, shared, bf->d_clock);
     } else {
         HIP_TRY(hipMemsetAsync(partial, 0xFF, (size_t)nq * 8, st));
         parts = 1;
@@ -513,6 +523,30 @@ static int bf_scan_into(orb_bf* bf, const uint8_t* d_q, int nq, uint64_t* d_pack
         orb_set_error("brute-force launch failed: %s", hipGetErrorString(e));
         return ORB_ERR_HIP;
     }
+    return ORB_OK;
+}
+
+extern "C" int orb_bf_clock_probe(orb_bf* bf, int enable, double* mhz) {
+    if (!bf) {
+        orb_set_error("orb_bf_clock_probe: bad arguments");
+        return ORB_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(bf->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (mhz) {
+        *mhz = 0.0;
+        if (bf->d_clock) {
+            unsigned long long v[2] = {0, 0};
+            HIP_TRY(hipMemcpy(v, bf->d_clock, 16, hipMemcpyDeviceToHost));
+            if (v[1]) *mhz = (double)v[0] / (double)v[1] * 100.0;  // the constant counter runs at 100 MHz
+        }
+    }
+    if (enable && !bf->d_clock) HIP_TRY(hipMalloc((void**)&bf->d_clock, 16));
+    if (!enable && bf->d_clock) {
+        (void)hipFree(bf->d_clock);
+        bf->d_clock = nullptr;
+    }
+    if (bf->d_clock) HIP_TRY(hipMemset(bf->d_clock, 0, 16));
     return ORB_OK;
 }
 

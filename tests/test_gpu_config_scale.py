@@ -149,3 +149,40 @@ def test_batch_of_64_kitti_frames(oracle):
     for f in (0, 21, 42, 63):
         _assert_frame_equal(binding, res[f], e.extract(imgs[f]), "KITTI-shaped frame %d" % f)
     c.close()
+
+
+def test_sharded_frame_job_does_not_depend_on_the_ranks(oracle):
+    """The benchmark's sharded frame job (tools/bench_configs.py config4: contiguous frame blocks per rank, no
+    exchange; the unit being sharded is one ORBextractor::operator() call, src/Frame.cc:67-74): the sum of the
+    per-frame output CRCs is the same for one rank and for three ranks run one after the other here (uneven blocks,
+    one of them shorter than a step), and a frame of the job equals the oracle's extraction of it."""
+    import os
+    import sys
+
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import bench_configs as bc
+
+    kw = dict(job=20, step_frames=6, w=1280, h=720, nf=1500, scenes=3)
+    one = bc.config4(bc.Ranks(), **kw)
+    assert one["frames_per_rank"] == 20 and one["mean_keypoints"] > 1000
+    got = []
+    for r in range(3):
+        # (a rank's "sum over ranks" here just records its share)
+        res = bc.config4(bc.Ranks(rank=r, world=3, sum_over_ranks=lambda x: x), **kw)
+        got.append(res)
+    assert [g["frames_per_rank"] for g in got] == [6, 7, 7]
+    assert sum(g["sum_of_frame_crc32"] for g in got) == one["sum_of_frame_crc32"]
+    # frame 7 of the job (scene 1 rolled by 10 columns) against the oracle
+    from orb_slam2_amd import binding
+
+    d = bc.job_frames(7, 8, 1280, 720, 4, 3, torch.device("cuda", 0))
+    img = d[0].cpu().numpy()
+    np.testing.assert_array_equal(img, np.roll(synth_scene(1280, 720, frame_seed(4, 1)), 10, axis=1))
+    ctx = binding.Context(1500, 1.2, 8, 20, 7, 1280, 720, 1, 0, FORK)
+    k, dsc = ctx.extract(img)
+    ko, do = oracle.Extractor(1500, 1.2, 8, 20, 7, oracle.QUIRKS_FORK).extract(img)
+    assert len(k) == len(ko) and (k == ko).all() and (dsc == do).all()
+    ctx.close()
