@@ -19,6 +19,7 @@
 #ifndef ORB_HIP_H
 #define ORB_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -88,9 +89,21 @@ int orb_extract(orb_ctx* ctx, const uint8_t* img, int w, int h, int stride, orb_
                 int* n_out);
 
 /* The same over n independent frames of one size (n <= max_batch).  Frame f
- * writes kps[f*cap_per_frame ..] and desc[f*cap_per_frame*32 ..], n_out[f]. */
+ * writes kps[f*cap_per_frame ..] and desc[f*cap_per_frame*32 ..], n_out[f].
+ * Frames in pageable memory are first copied into page-locked staging by host
+ * threads the context keeps (the host's memory rate bounds that copy, for all
+ * contexts of a machine together); frames that already lie in page-locked
+ * memory (orb_alloc_host, hipHostMalloc, hipHostRegister - the call finds out
+ * by itself) are fetched by the DMA engine from where they are, as one copy per
+ * frame group when they follow each other stride*h bytes apart. */
 int orb_extract_batch(orb_ctx* ctx, const uint8_t* const* imgs, int n, int w, int h, int stride, orb_keypoint* kps,
                       uint8_t* desc, int cap_per_frame, int* n_out);
+
+/* Page-locked host memory for frames (no counterpart in the reference): what a
+ * capture loop reads its images into so that orb_extract_batch needs no staging
+ * copy.  Usable from every device. */
+int orb_alloc_host(size_t bytes, void** out);
+void orb_free_host(void* p);
 
 /* The same with every buffer resident in device memory: frame f starts at
  * d_imgs + f*frame_stride.  Asynchronous on `stream`. */
@@ -379,6 +392,20 @@ int orb_bf_multi_query_top2(orb_bf_multi* m, const uint8_t* q, int nq, int32_t* 
  * depend on nctx. */
 int orb_extract_batch_multi(orb_ctx* const* ctxs, int nctx, const uint8_t* const* imgs, int n, int w, int h, int stride,
                             orb_keypoint* kps, uint8_t* desc, int cap_per_frame, int* n_out);
+/* (Page-locked frames: the calling thread enqueues every context's block and
+ * collects them in turn, no host thread is made and no host copy stands between
+ * the frames and the link.  Pageable frames: one host thread per context.)
+ *
+ * The same split with block r resident on ctxs[r]'s device: d_imgs[r],
+ * d_kps[r], d_desc[r], d_n_out[r] are that block's buffers (frame f of the
+ * block at d_imgs[r] + f*frame_stride, outputs as orb_extract_batch_device).
+ * One enqueue per context from the calling thread, no host thread, no copy.
+ * streams[r] is the stream block r runs on and the call returns at once;
+ * streams == NULL runs every block on its context's own stream and waits for
+ * all of them. */
+int orb_extract_batch_multi_device(orb_ctx* const* ctxs, int nctx, const uint8_t* const* d_imgs, int n, int w, int h,
+                                   int stride, int64_t frame_stride, orb_keypoint* const* d_kps, uint8_t* const* d_desc,
+                                   int cap_per_frame, int* const* d_n_out, void* const* streams);
 
 /* ---- bag of words: DBoW2 vocabulary tree and SearchByBoW ----------------------- */
 

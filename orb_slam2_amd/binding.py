@@ -32,7 +32,7 @@ EXPORTS = [
     "orb_match_window_batch_device", "orb_match_reserve_candidates", "orb_match_projected", "orb_bf_create", "orb_bf_destroy", "orb_bf_set_database",
     "orb_bf_set_database_device", "orb_bf_query_top2", "orb_bf_query_packed_device", "orb_bf_query_packed_noalloc", "orb_bf_clock_probe", "orb_bf_merge_packed_device",
     "orb_bf_multi_create", "orb_bf_multi_destroy", "orb_bf_multi_exchange", "orb_bf_multi_set_database",
-    "orb_bf_multi_query_top2", "orb_extract_batch_multi",
+    "orb_bf_multi_query_top2", "orb_extract_batch_multi", "orb_extract_batch_multi_device", "orb_alloc_host", "orb_free_host",
     "orb_enable_stage_timing", "orb_get_stage_timings", "orb_last_error", "orb_version",
     "orb_distinctive_descriptors", "orb_distinctive_descriptors_device",
     "orb_undistort_keypoints", "orb_undistort_keypoints_device", "orb_compute_image_bounds", "orb_set_image_bounds",
@@ -493,6 +493,44 @@ def extract_batch_multi(contexts, imgs):
     cnt = np.zeros(n, np.int32)
     _check(lib().orb_extract_batch_multi(hs, len(contexts), ptrs, n, w, h, imgs[0].strides[0], _p(kps), _p(desc), cap, _p(cnt)))
     return [(kps[f, : cnt[f]].copy(), desc[f, : cnt[f]].copy()) for f in range(n)]
+
+
+def extract_batch_multi_device(contexts, d_blocks, d_kps, d_desc, d_counts, streams=None):
+    """orb_extract_batch_multi_device: block r = d_blocks[r] (uint8 CUDA tensor [n_r, h, w] on contexts[r]'s device) with
+    outputs d_kps[r] [n_r, cap, 28], d_desc[r] [n_r, cap, 32], d_counts[r] [n_r].  The block sizes must be the
+    contiguous split of their total over the contexts.  streams: torch streams, one per context (asynchronous), or None
+    (the contexts' own streams; returns when all blocks are done)."""
+    R = len(contexts)
+    n = sum(int(b.shape[0]) for b in d_blocks)
+    assert [int(b.shape[0]) for b in d_blocks] == [(n * (r + 1)) // R - (n * r) // R for r in range(R)]
+    ref = next(b for b in d_blocks if b.shape[0] > 0)
+    h, w = int(ref.shape[1]), int(ref.shape[2])
+    assert all(b.shape[0] == 0 or (b.shape[1:] == ref.shape[1:] and b.stride() == ref.stride()) for b in d_blocks)
+    cap = int(d_kps[0].shape[1])
+    arr = lambda ts: (C.c_void_p * R)(*[t.data_ptr() if t.shape[0] > 0 else None for t in ts])
+    hs = (C.c_void_p * R)(*[c.h for c in contexts])
+    st = (C.c_void_p * R)(*[s.cuda_stream for s in streams]) if streams is not None else None
+    _check(lib().orb_extract_batch_multi_device(hs, R, arr(d_blocks), n, w, h, ref.stride(1), C.c_int64(ref.stride(0)), arr(d_kps),
+                                                arr(d_desc), cap, arr(d_counts), st))
+
+
+def alloc_host(shape, dtype=np.uint8):
+    """A numpy array over page-locked host memory (orb_alloc_host): frames kept in it reach the device without a
+    staging copy.  The memory is released when the array (and every view of it) is gone."""
+    shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    _check(lib().orb_alloc_host(C.c_size_t(max(nbytes, 1)), C.byref(p)))
+    free = lib().orb_free_host
+    addr = p.value
+
+    class _Owner:
+        def __del__(self):
+            free(C.c_void_p(addr))
+
+    buf = (C.c_ubyte * max(nbytes, 1)).from_address(addr)
+    buf._owner = _Owner()  # the ctypes block keeps the owner alive; numpy keeps the ctypes block as its base
+    return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
 
 def merge_packed_device(device, d_gathered, nshards, nq, d_idx, d_best, d_second, stream=None):

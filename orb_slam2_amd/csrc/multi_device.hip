@@ -302,36 +302,55 @@ extern "C" int orb_bf_multi_query_top2(orb_bf_multi* m, const uint8_t* q, int nq
     return ORB_OK;
 }
 
+// defined beside orb_extract_batch (orb_api.hip), whose two halves they use
+int orb_extract_batch_over_contexts(orb_ctx* const* ctxs, int nctx, const uint8_t* const* imgs, int n, int w, int h, int stride,
+                                    orb_keypoint* kps, uint8_t* desc, int cap_per_frame, int* n_out);
+int orb_extract_batch_over_contexts_device(orb_ctx* const* ctxs, int nctx, const uint8_t* const* d_imgs, int n, int w, int h,
+                                           int stride, int64_t frame_stride, orb_keypoint* const* d_kps, uint8_t* const* d_desc,
+                                           int cap_per_frame, int* const* d_n_out, void* const* streams);
+
+static int check_contexts(const char* who, orb_ctx* const* ctxs, int nctx) {
+    if (!ctxs || nctx < 1) {
+        orb_set_error("%s: bad arguments", who);
+        return ORB_ERR_INVALID;
+    }
+    for (int r = 0; r < nctx; r++) {
+        if (!ctxs[r]) {
+            orb_set_error("%s: context %d is null", who, r);
+            return ORB_ERR_INVALID;
+        }
+        for (int s = 0; s < r; s++)
+            if (ctxs[s] == ctxs[r]) {
+                orb_set_error("%s: contexts %d and %d are the same (a context runs one block at a time)", who, s, r);
+                return ORB_ERR_INVALID;
+            }
+    }
+    return ORB_OK;
+}
+
 extern "C" int orb_extract_batch_multi(orb_ctx* const* ctxs, int nctx, const uint8_t* const* imgs, int n, int w, int h,
                                        int stride, orb_keypoint* kps, uint8_t* desc, int cap_per_frame, int* n_out) {
-    if (!ctxs || nctx < 1 || !imgs || n < 0 || !n_out) {
+    int rc = check_contexts("orb_extract_batch_multi", ctxs, nctx);
+    if (rc) return rc;
+    if (!imgs || n < 0 || !n_out) {
         orb_set_error("orb_extract_batch_multi: bad arguments");
         return ORB_ERR_INVALID;
     }
-    for (int r = 0; r < nctx; r++)
-        if (!ctxs[r]) {
-            orb_set_error("orb_extract_batch_multi: context %d is null", r);
-            return ORB_ERR_INVALID;
-        }
-    // contiguous frame blocks [r n / R, (r + 1) n / R), one host thread per context; results land in the caller's
-    // arrays at the frames' own places, so the outcome does not depend on the number of contexts
-    std::vector<int> rcs(nctx, ORB_OK);
-    std::vector<std::string> msgs(nctx);
-    auto work = [&](int r) {
-        const int lo = (int)((int64_t)n * r / nctx), hi = (int)((int64_t)n * (r + 1) / nctx);
-        if (hi == lo) return;
-        rcs[r] = orb_extract_batch(ctxs[r], imgs + lo, hi - lo, w, h, stride, kps ? kps + (size_t)lo * cap_per_frame : nullptr,
-                                   desc ? desc + (size_t)lo * cap_per_frame * 32 : nullptr, cap_per_frame, n_out + lo);
-        if (rcs[r]) msgs[r] = orb_last_error();
-    };
-    std::vector<std::thread> th;
-    for (int r = 1; r < nctx; r++) th.emplace_back(work, r);
-    work(0);
-    for (std::thread& t : th) t.join();
-    for (int r = 0; r < nctx; r++)
-        if (rcs[r]) {
-            orb_set_error("frame block %d: %s", r, msgs[r].c_str());
-            return rcs[r];
-        }
-    return ORB_OK;
+    // contiguous frame blocks [r n / R, (r + 1) n / R); results land in the caller's arrays at the frames' own
+    // places, so the outcome does not depend on the number of contexts
+    return orb_extract_batch_over_contexts(ctxs, nctx, imgs, n, w, h, stride, kps, desc, cap_per_frame, n_out);
+}
+
+extern "C" int orb_extract_batch_multi_device(orb_ctx* const* ctxs, int nctx, const uint8_t* const* d_imgs, int n, int w, int h,
+                                              int stride, int64_t frame_stride, orb_keypoint* const* d_kps,
+                                              uint8_t* const* d_desc, int cap_per_frame, int* const* d_n_out,
+                                              void* const* streams) {
+    int rc = check_contexts("orb_extract_batch_multi_device", ctxs, nctx);
+    if (rc) return rc;
+    if (!d_imgs || !d_kps || !d_desc || !d_n_out || n < 0 || w <= 0 || h <= 0) {
+        orb_set_error("orb_extract_batch_multi_device: bad arguments");
+        return ORB_ERR_INVALID;
+    }
+    return orb_extract_batch_over_contexts_device(ctxs, nctx, d_imgs, n, w, h, stride, frame_stride, d_kps, d_desc,
+                                                  cap_per_frame, d_n_out, streams);
 }

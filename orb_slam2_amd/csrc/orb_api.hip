@@ -10,6 +10,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
@@ -87,6 +90,73 @@ struct PinBuf {  // page-locked host staging: one DMA per direction instead of p
     }
 };
 
+// Host threads a context keeps for staging batches of pageable frames (created when the first such batch arrives,
+// asleep on a condition variable between batches): run(n, fn) calls fn(0) on the caller and fn(1) .. fn(n - 1) on
+// the workers and returns when all have finished.
+class StagePool {
+public:
+    ~StagePool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cvStart_.notify_all();
+        for (std::thread& t : th_) t.join();
+    }
+    void run(int nthreads, const std::function<void(int)>& fn) {
+        if (nthreads <= 1) {
+            fn(0);
+            return;
+        }
+        while ((int)th_.size() < nthreads - 1) {
+            const int id = (int)th_.size() + 1;
+            th_.emplace_back([this, id] { worker(id); });
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &fn;
+            active_ = nthreads;
+            pending_ = nthreads - 1;
+            gen_++;
+        }
+        cvStart_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(m_);
+        cvDone_.wait(lk, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+private:
+    void worker(int id) {
+        unsigned seen = 0;
+        for (;;) {
+            const std::function<void(int)>* job = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cvStart_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                if (id < active_) job = job_;
+            }
+            if (!job) continue;
+            (*job)(id);
+            bool last;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                last = --pending_ == 0;
+            }
+            if (last) cvDone_.notify_one();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cvStart_, cvDone_;
+    const std::function<void(int)>* job_ = nullptr;
+    unsigned gen_ = 0;
+    int active_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+
 #define ORB_MAX_PARTS 4
 #define ORB_STAGE_THREADS 16     // most host threads that stage a batch of host frames (orb_ctx::stageThreads are used)
 #define ORB_STAGE_SLICE 4        // batches below this many frames are staged and copied in one piece
@@ -111,8 +181,9 @@ struct orb_ctx {
     // levels) run under the throughput-bound stages of another.
     hipStream_t aux[ORB_MAX_PARTS - 1] = {};
     hipEvent_t evFork = nullptr, evJoin[ORB_MAX_PARTS - 1] = {};
-    hipEvent_t evIn = nullptr;  // host-pointer batches: the frames of every group but the first have arrived
+    hipEvent_t evIn[ORB_MAX_PARTS] = {};  // host-pointer batches: entry i marks the arrival of frame group i's frames (i >= 1)
     int parts = 2;
+    int hostParts = 3;  // frame groups of a host-pointer batch: the groups are also what overlaps the frames' way over the link with the extraction
     int stageThreads = 4;
     DevBuf dGeom, dAreaTaps, dLinTaps, dCodeTab, dInput, dPyr, dCellKeys, dCellCount, dSort, dNodes, dInts,
         dSelXY, dSelScore, dLevelCount, dLevelKeys, dQtRetry, dTmpA, dTmpB;
@@ -123,6 +194,15 @@ struct orb_ctx {
     DevBuf dHostOut;
     int* dErr() const { return (int*)dHostOut.p; }
     PinBuf pinIn, pinOut;  // host-pointer entry points only, sized on first use
+    StagePool* pool = nullptr;  // staging threads of the host-pointer entry points, made on first use
+    // a host-pointer batch between its two halves (extract_batch_begin / extract_batch_finish)
+    struct {
+        bool open = false, direct = false;
+        int n = 0, cap = 0;
+        int ngroups = 1, groupStart[ORB_MAX_PARTS + 1] = {};  // group i > 0 = frames [groupStart[i], groupStart[i + 1]), done at evJoin[i - 1]
+        double t0 = 0;               // ORBHIP_HOST_TRACE: when the call began
+        size_t offCnt = 0, offKps = 0, offDesc = 0, total = 0;
+    } hostBatch;
     int lastFrames = 0;
     int lastGroups = 0, lastGroupFrame0[ORB_MAX_PARTS] = {};  // frame groups of the last batch whose quadtree ran in two passes
     int inputStride = 0;
@@ -618,7 +698,7 @@ static int ensure_buffers(orb_ctx* c, int n) {
     if ((rc = c->dQtRetry.ensure(((size_t)n * (g.nlevels + 1) + 1) * 4))) return rc;
     if (!c->dHostOut.p) {
         const size_t frames = (size_t)std::max(n, c->prm.max_batch), cap = (size_t)orb_max_keypoints_per_frame(c);
-        if ((rc = c->dHostOut.ensure(64 + ((frames * 4 + 63) & ~(size_t)63) + frames * cap * (sizeof(orb_keypoint) + 32)))) return rc;
+        if ((rc = c->dHostOut.ensure(64 + 2 * ((frames * 4 + 63) & ~(size_t)63) + frames * cap * (sizeof(orb_keypoint) + 32)))) return rc;
         HIP_TRY(hipMemset(c->dHostOut.p, 0, 64));
     }
     return ORB_OK;
@@ -667,14 +747,15 @@ extern "C" int orb_create(const orb_params* prm, orb_ctx** out) {
     CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     // one extra stream per frame group beyond the first: a process has few hardware queues (four by default),
     // and streams that share one serialise, so a context takes no more than it will use
-    if (const char* e = getenv("ORBHIP_PARTS")) c->parts = std::max(1, std::min(ORB_MAX_PARTS, atoi(e)));
+    if (const char* e = getenv("ORBHIP_PARTS")) c->parts = c->hostParts = std::max(1, std::min(ORB_MAX_PARTS, atoi(e)));
+    if (const char* e = getenv("ORBHIP_HOST_PARTS")) c->hostParts = std::max(1, std::min(ORB_MAX_PARTS, atoi(e)));
     if (const char* e = getenv("ORBHIP_STAGE_THREADS")) c->stageThreads = std::max(1, std::min(ORB_STAGE_THREADS, atoi(e)));
-    for (int i = 0; i < c->parts - 1; i++) {
+    for (int i = 0; i < std::max(c->parts, c->hostParts) - 1; i++) {
         CREATE_TRY(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking));
         CREATE_TRY(hipEventCreateWithFlags(&c->evJoin[i], hipEventDisableTiming));
     }
     CREATE_TRY(hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
-    CREATE_TRY(hipEventCreateWithFlags(&c->evIn, hipEventDisableTiming));
+    for (int i = 1; i < ORB_MAX_PARTS; i++) CREATE_TRY(hipEventCreateWithFlags(&c->evIn[i], hipEventDisableTiming));
 #undef CREATE_TRY
     // size everything for the largest announced frame and batch now, so steady-state calls allocate nothing
     int rc = compute_geom(c, prm->max_width, prm->max_height);
@@ -702,6 +783,8 @@ extern "C" void orb_destroy(orb_ctx* c) {
     for (DevBuf* b : bufs) b->release();
     c->pinIn.release();
     c->pinOut.release();
+    delete c->pool;
+    c->pool = nullptr;
     if (c->matchState) orb_match_state_free(c->matchState);
     if (c->bowState) orb_bow_state_free(c->bowState);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -710,7 +793,8 @@ extern "C" void orb_destroy(orb_ctx* c) {
         if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
     }
     if (c->evFork) (void)hipEventDestroy(c->evFork);
-    if (c->evIn) (void)hipEventDestroy(c->evIn);
+    for (hipEvent_t e : c->evIn)
+        if (e) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -756,12 +840,12 @@ extern "C" int orb_compute_tables(const orb_params* prm, float* scale, float* in
 // Frame groups a batch of n frames is enqueued as (group i = frames [n i / parts, n (i + 1) / parts)).
 static int batch_parts(const orb_ctx* c, int n) { return c->timing ? 1 : std::max(1, std::min(c->parts, n / ORB_MIN_PART_FRAMES)); }
 
-// Enqueue the whole extraction for n frames whose level 0 is at d_img0.  laterGroupsInput, when given, is an event
-// after which the frames of every group but the first are in place (the first group's are by the time the stream
-// reaches its kernels): those groups then wait for it instead of for the stream's earlier work.
+// Enqueue the whole extraction for n frames whose level 0 is at d_img0.  groupInput, when given, holds per frame group
+// i >= 1 an event after which that group's frames are in place (the first group's are by the time the stream reaches
+// its kernels): those groups then wait for their events instead of for the stream's earlier work.
 static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int stride, int64_t frameStride,
                      orb_keypoint* d_kps, uint8_t* d_desc, int cap, int* d_nOut, hipStream_t st, int* d_status = nullptr,
-                     hipEvent_t laterGroupsInput = nullptr) {
+                     const hipEvent_t* groupInput = nullptr, const int* groupStart = nullptr, int ngroups = 0) {
     if (n < 1 || n > c->prm.max_batch) {
         orb_set_error("batch of %d frames outside 1..max_batch=%d", n, c->prm.max_batch);
         return ORB_ERR_INVALID;
@@ -840,17 +924,22 @@ static int run_batch(orb_ctx* c, const uint8_t* d_img0, int n, int w, int h, int
         HIP_TRY(hipEventRecord(ev[4], st));
         return ORB_OK;
     }
-    const int parts = batch_parts(c, n);
-    if (parts > 1 && !laterGroupsInput) HIP_TRY(hipEventRecord(c->evFork, st));
+    // groups: the caller's (groupStart[0 .. ngroups], first 0, last n) or equal shares
+    const int parts = groupStart ? ngroups : batch_parts(c, n);
+    if (parts > 1 && !groupInput) HIP_TRY(hipEventRecord(c->evFork, st));
     // stage by stage across the groups, so that the queues hold comparable work at any time
     OrbBatch pb[ORB_MAX_PARTS];
     for (int i = 0; i < parts; i++) {
         pb[i] = b;
         pb[i].frame0 = (int)((int64_t)n * i / parts);
         pb[i].nframes = (int)((int64_t)n * (i + 1) / parts) - pb[i].frame0;
+        if (groupStart) {
+            pb[i].frame0 = groupStart[i];
+            pb[i].nframes = groupStart[i + 1] - groupStart[i];
+        }
         if (i > 0) {
             pb[i].stream = c->aux[i - 1];
-            HIP_TRY(hipStreamWaitEvent(c->aux[i - 1], laterGroupsInput ? laterGroupsInput : c->evFork, 0));
+            HIP_TRY(hipStreamWaitEvent(c->aux[i - 1], groupInput ? groupInput[i] : c->evFork, 0));
         }
     }
     c->lastGroups = 0;
@@ -971,6 +1060,275 @@ extern "C" int orb_extract_batch_device(orb_ctx* c, const uint8_t* d_imgs, int n
                      (hipStream_t)stream);
 }
 
+// Are the n frames (each `bytes` long) in page-locked host memory (hipHostMalloc, hipHostRegister, orb_alloc_host)?
+// The DMA engine can then fetch them where they are.  One range query covers every frame of the same allocation.
+static bool frames_page_locked(const uint8_t* const* imgs, int n, size_t bytes) {
+    const uint8_t *lo = nullptr, *hi = nullptr;  // the page-locked range found last
+    for (int f = 0; f < n; f++) {
+        const uint8_t* p = imgs[f];
+        if (lo && p >= lo && p + bytes <= hi) continue;
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+            (void)hipGetLastError();  // (an ordinary pointer is reported as an error: not one of ours)
+            return false;
+        }
+        if (a.type != hipMemoryTypeHost) return false;
+        void* base = nullptr;
+        size_t size = 0;
+        if (hipPointerGetAttribute(&base, HIP_POINTER_ATTRIBUTE_RANGE_START_ADDR, (hipDeviceptr_t)p) != hipSuccess ||
+            hipPointerGetAttribute(&size, HIP_POINTER_ATTRIBUTE_RANGE_SIZE, (hipDeviceptr_t)p) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        lo = (const uint8_t*)base;
+        hi = lo + size;
+        if (!(p >= lo && p + bytes <= hi)) return false;
+    }
+    return true;
+}
+
+// First half of a host-pointer batch: the frames' way to the device, the extraction and the copy of the result block
+// are enqueued on the context's stream; nothing is waited for.  pinnedHint: 1 / 0 when the caller has already
+// looked where the frames live, -1 to find out here.
+static int extract_batch_begin(orb_ctx* c, const uint8_t* const* imgs, int n, int w, int h, int stride, bool wantKps,
+                               bool wantDesc, int pinnedHint) {
+    if (n < 1 || n > c->prm.max_batch || w > c->prm.max_width || h > c->prm.max_height || stride < w) {
+        orb_set_error("orb_extract_batch: batch %d / frame %dx%d stride %d outside the context's limits", n, w, h,
+                      stride);
+        return ORB_ERR_INVALID;
+    }
+    if (c->hostBatch.open) {
+        orb_set_error("orb_extract_batch: the context's previous host-pointer batch has not been collected");
+        return ORB_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(c->prm.device));
+    int rc = compute_geom(c, w, h);
+    if (rc) return rc;
+    const int cap = orb_max_keypoints_per_frame(c);
+    const int dstride = c->inputStride;
+    const int64_t fstride = (int64_t)dstride * h;
+    for (int f = 0; f < n; f++)
+        if (!imgs[f]) {
+            orb_set_error("frame %d is null", f);
+            return ORB_ERR_INVALID;
+        }
+    const size_t frameBytes = (size_t)stride * (h - 1) + w;
+    const bool pinned = pinnedHint >= 0 ? pinnedHint != 0 : frames_page_locked(imgs, n, frameBytes);
+    const bool few = n < ORB_STAGE_SLICE;
+    static const bool trace = getenv("ORBHIP_HOST_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double T0 = now();
+    const hipEvent_t* groupIn = nullptr;
+    // Frame groups: the frames of the later groups travel first, group by group, each group starts extracting when
+    // its own frames have arrived, and its results are unpacked on the host while the groups behind it still run.
+    // What remains once the last frame has arrived is the first group's extraction.  Three equal groups by default
+    // (64 page-locked frames: 0.70 ms against 0.735 with two; a smaller first group, ORBHIP_HOST_FIRST_PCT, gained
+    // nothing: consecutive copies leave some 35 us between them and small groups are bound by their launches).
+    const int parts = (few || c->timing) ? 1 : std::max(1, std::min(c->hostParts, n / ORB_MIN_PART_FRAMES));
+    int gs[ORB_MAX_PARTS + 1] = {0};
+    {
+        static const int pct = getenv("ORBHIP_HOST_FIRST_PCT") ? atoi(getenv("ORBHIP_HOST_FIRST_PCT")) : 0;
+        const int first = parts > 1 ? std::max(ORB_MIN_PART_FRAMES, std::min(n - ORB_MIN_PART_FRAMES * (parts - 1), pct > 0 ? n * pct / 100 : n / parts)) : n;
+        for (int i = 1; i <= parts; i++) gs[i] = first + (int)((int64_t)(n - first) * (i - 1) / std::max(1, parts - 1));
+        gs[parts] = n;
+    }
+    if (pinned) {
+        // Page-locked frames go to the device from where they are: no staging copy on the host (which runs at the
+        // host memory's rate, and at that rate for all contexts of a node together).  Frames that follow each other
+        // at a fixed distance travel as one copy per frame group, the later groups' first (those groups extract while
+        // the first group's frames are still on the link); frames scattered over the heap as one copy each.
+        auto copy_run = [&](int f0, int f1) -> hipError_t {
+            bool uniform = true;
+            for (int f = f0; f + 1 < f1 && uniform; f++) uniform = imgs[f + 1] - imgs[f] == (ptrdiff_t)stride * h;
+            uint8_t* dst = (uint8_t*)c->dInput.p + (size_t)f0 * fstride;
+            if (uniform && stride == dstride)
+                return hipMemcpyAsync(dst, imgs[f0], (size_t)(f1 - f0 - 1) * fstride + frameBytes, hipMemcpyHostToDevice, c->stream);
+            if (uniform)
+                return hipMemcpy2DAsync(dst, (size_t)dstride, imgs[f0], (size_t)stride, (size_t)w, (size_t)(f1 - f0) * h,
+                                        hipMemcpyHostToDevice, c->stream);
+            for (int f = f0; f < f1; f++) {
+                uint8_t* df = (uint8_t*)c->dInput.p + (size_t)f * fstride;
+                const hipError_t e = stride == dstride
+                                         ? hipMemcpyAsync(df, imgs[f], frameBytes, hipMemcpyHostToDevice, c->stream)
+                                         : hipMemcpy2DAsync(df, (size_t)dstride, imgs[f], (size_t)stride, (size_t)w, (size_t)h,
+                                                            hipMemcpyHostToDevice, c->stream);
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
+        };
+        for (int i = 1; i < parts; i++) {
+            HIP_TRY(copy_run(gs[i], gs[i + 1]));
+            HIP_TRY(hipEventRecord(c->evIn[i], c->stream));
+        }
+        HIP_TRY(copy_run(0, parts > 1 ? gs[1] : n));
+        if (parts > 1) groupIn = c->evIn;
+    } else {
+        // Pageable frames -> page-locked staging in the device layout (row copies on the host) -> device.  A single
+        // host thread copies at a fraction of the link rate, so a batch is staged by up to four threads (the context
+        // keeps them), slice by slice, and every slice is handed to the DMA engine as soon as it is staged (host
+        // copies and DMA overlap).  The copies go to ONE stream, in a fixed order (copies on several streams at once
+        // share the link badly: 17 instead of 56 GB/s), in slices of about 5 MB (consecutive copies on a stream leave
+        // 18 us between them and cost the enqueuing thread 15 us each: 1.2 MB slices ran at 35 GB/s; a kernel that
+        // reads the staging block over the link itself has no such gaps but is slower, 0.89 against 0.82 ms for 64
+        // frames).  The frames of the later frame groups go first and an event marks their arrival: those groups
+        // start extracting while the first group's frames, the last to arrive, are still on the link.
+        if ((rc = c->pinIn.ensure((size_t)n * fstride))) return rc;
+        auto stage_frames = [&](int f0, int f1) {
+            for (int f = f0; f < f1; f++) {
+                uint8_t* dst = (uint8_t*)c->pinIn.p + f * fstride;
+                if (stride == dstride) {
+                    memcpy(dst, imgs[f], frameBytes);
+                } else {
+                    for (int r = 0; r < h; r++) memcpy(dst + (size_t)r * dstride, imgs[f] + (size_t)r * stride, (size_t)w);
+                }
+            }
+        };
+        if (few) {
+            // a few frames (the reference's one-frame-per-call use): one host thread, one copy
+            stage_frames(0, n);
+            HIP_TRY(hipMemcpyAsync(c->dInput.p, c->pinIn.p, (size_t)n * fstride, hipMemcpyHostToDevice, c->stream));
+        } else {
+            const int per = (int)std::max<int64_t>(1, std::min<int64_t>(n, ORB_STAGE_SLICE_BYTES / fstride));
+            int sl0[ORB_MAX_STAGE_SLICES], sl1[ORB_MAX_STAGE_SLICES], slEv[ORB_MAX_STAGE_SLICES], nsl = 0;
+            // (a slice holds at least n / 25 frames: the runs below, one per group and each ending in a shorter slice,
+            // make at most 25 + ORB_MAX_PARTS slices)
+            const int perCapped = std::max(per, (n + 24) / 25);
+            for (int i = 1; i <= parts; i++) {  // groups 1 .. parts - 1, then group 0
+                const int gi = i < parts ? i : 0, f0 = gs[gi], f1 = gs[gi + 1];
+                for (int s0 = f0; s0 < f1; s0 += perCapped) {
+                    sl0[nsl] = s0;
+                    sl1[nsl] = std::min(f1, s0 + perCapped);
+                    slEv[nsl++] = (gi > 0 && s0 + perCapped >= f1) ? gi : 0;  // the group's last slice records its event
+                }
+            }
+            // every slice is staged by all the threads together, a share of its frames each; whoever finishes a slice's
+            // last share hands the slice to the DMA engine.  A thread takes the slices in order, so the last share of
+            // slice k is finished after its owner has enqueued every earlier slice it completed: copies are enqueued
+            // in slice order without any waiting.
+            const int nthreads = std::max(1, std::min(c->stageThreads, n / ORB_STAGE_SLICE));
+            hipError_t terr[ORB_STAGE_THREADS];
+            std::atomic<int> arrived[ORB_MAX_STAGE_SLICES];
+            for (int k = 0; k < nsl; k++) arrived[k].store(0, std::memory_order_relaxed);
+            const std::function<void(int)> stage = [&](int t) {
+                terr[t] = t ? hipSetDevice(c->prm.device) : hipSuccess;
+                for (int k = 0; k < nsl; k++) {
+                    const int m = sl1[k] - sl0[k];
+                    stage_frames(sl0[k] + m * t / nthreads, sl0[k] + m * (t + 1) / nthreads);
+                    if (arrived[k].fetch_add(1, std::memory_order_acq_rel) + 1 < nthreads || terr[t] != hipSuccess) continue;
+                    const size_t off = (size_t)sl0[k] * fstride;
+                    terr[t] = hipMemcpyAsync((uint8_t*)c->dInput.p + off, (uint8_t*)c->pinIn.p + off, (size_t)m * fstride,
+                                             hipMemcpyHostToDevice, c->stream);
+                    if (terr[t] == hipSuccess && slEv[k]) terr[t] = hipEventRecord(c->evIn[slEv[k]], c->stream);
+                }
+            };
+            if (nthreads > 1 && !c->pool) c->pool = new StagePool();
+            if (nthreads > 1) c->pool->run(nthreads, stage);
+            else stage(0);
+            for (int t = 0; t < nthreads; t++) HIP_TRY(terr[t]);
+            if (parts > 1) groupIn = c->evIn;
+        }
+    }
+    // results: [flag words, one per frame | counts | keypoints (cap per frame) | descriptors] as one block in
+    // page-locked host memory, which the last kernel writes over the link itself (a copy after the kernels, and the
+    // gap before it, cost more than the 64 KB per frame take), with the flag word as the last stage saw it per
+    // frame.  ORBHIP_HOST_RESULT_COPY=1 keeps the block on the device and fetches it with one copy instead.
+    const double T1 = now();
+    const size_t offCnt = std::max<size_t>(64, ((size_t)n * 4 + 63) & ~(size_t)63), offKps = offCnt + (((size_t)n * 4 + 63) & ~(size_t)63);
+    const size_t offDesc = offKps + (size_t)n * cap * sizeof(orb_keypoint);
+    const size_t total = offDesc + (size_t)n * cap * 32;
+    if ((rc = c->pinOut.ensure(total))) return rc;
+    uint8_t* po = (uint8_t*)c->pinOut.p;
+    static const bool resultCopy = getenv("ORBHIP_HOST_RESULT_COPY") != nullptr;
+    const bool direct = few || !resultCopy;
+    if (direct) {
+        uint8_t* dpo = nullptr;  // the block as the device addresses it
+        HIP_TRY(hipHostGetDevicePointer((void**)&dpo, po, 0));
+        rc = run_batch(c, (const uint8_t*)c->dInput.p, n, w, h, dstride, fstride, (orb_keypoint*)(dpo + offKps), dpo + offDesc,
+                       cap, (int*)(dpo + offCnt), c->stream, (int*)dpo, groupIn, parts > 1 ? gs : nullptr, parts);
+        if (rc) return rc;
+    } else {
+        if (c->dHostOut.bytes < total) {
+            orb_set_error("internal: result block of %zu bytes beyond the context's", total);
+            return ORB_ERR_CAPACITY;
+        }
+        uint8_t* dOut = (uint8_t*)c->dHostOut.p;
+        rc = run_batch(c, (const uint8_t*)c->dInput.p, n, w, h, dstride, fstride, (orb_keypoint*)(dOut + offKps), dOut + offDesc,
+                       cap, (int*)(dOut + offCnt), c->stream, nullptr, groupIn, parts > 1 ? gs : nullptr, parts);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(po, dOut, (wantKps || wantDesc) ? (wantDesc ? total : offDesc) : offKps, hipMemcpyDeviceToHost, c->stream));
+    }
+    c->hostBatch.t0 = T0;
+    c->hostBatch.open = true;
+    c->hostBatch.direct = direct;
+    c->hostBatch.ngroups = (direct && !c->timing) ? parts : 1;
+    for (int i = 0; i <= parts; i++) c->hostBatch.groupStart[i] = gs[i];
+    c->hostBatch.n = n;
+    c->hostBatch.cap = cap;
+    c->hostBatch.offCnt = offCnt;
+    c->hostBatch.offKps = offKps;
+    c->hostBatch.offDesc = offDesc;
+    c->hostBatch.total = total;
+    if (trace) fprintf(stderr, "host batch %d (%s frames): input enqueued after %.0f us, kernels and result copy after %.0f us\n", n, pinned ? "page-locked" : "pageable", T1 - T0, now() - T0);
+    return ORB_OK;
+}
+
+// Second half: waits for the context's stream and unpacks the result block into the caller's arrays.
+static int extract_batch_finish(orb_ctx* c, orb_keypoint* kps, uint8_t* desc, int cap_per_frame, int* n_out) {
+    if (!c->hostBatch.open) {
+        orb_set_error("orb_extract_batch: no batch to collect");
+        return ORB_ERR_INVALID;
+    }
+    c->hostBatch.open = false;
+    HIP_TRY(hipSetDevice(c->prm.device));
+    const int n = c->hostBatch.n, cap = c->hostBatch.cap, ngroups = c->hostBatch.ngroups;
+    const int* gs = c->hostBatch.groupStart;
+    const size_t offCnt = c->hostBatch.offCnt, offKps = c->hostBatch.offKps, offDesc = c->hostBatch.offDesc;
+    uint8_t* po = (uint8_t*)c->pinOut.p;
+    auto unpack = [&](int f0, int f1) -> int {
+        memcpy(n_out + f0, po + offCnt + (size_t)f0 * 4, (size_t)(f1 - f0) * 4);
+        for (int f = f0; f < f1; f++) {
+            const int m = n_out[f];
+            if (m > cap_per_frame) {
+                orb_set_error("frame %d produced %d keypoints, caller capacity is %d", f, m, cap_per_frame);
+                return ORB_ERR_CAPACITY;
+            }
+            if (m > 0) {
+                if (kps)
+                    memcpy(kps + (size_t)f * cap_per_frame, po + offKps + (size_t)f * cap * sizeof(orb_keypoint),
+                           (size_t)m * sizeof(orb_keypoint));
+                if (desc) memcpy(desc + (size_t)f * cap_per_frame * 32, po + offDesc + (size_t)f * cap * 32, (size_t)m * 32);
+            }
+        }
+        return ORB_OK;
+    };
+    auto flagged = [&](int f0, int f1) {
+        int any = 0;
+        for (int f = f0; f < f1; f++) any |= ((const int*)po)[f];
+        return any != 0;
+    };
+    static const bool trace = getenv("ORBHIP_HOST_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tA = 0, tB = 0, tC = 0;
+    int rc = ORB_OK;
+    // the later groups are done first (their frames arrived first), in turn: their results are unpacked while the
+    // first group still extracts
+    for (int i = 1; i < ngroups && rc == ORB_OK; i++) {
+        HIP_TRY(hipEventSynchronize(c->evJoin[i - 1]));
+        if (i == 1) tA = now();
+        if (!flagged(gs[i], gs[i + 1])) rc = unpack(gs[i], gs[i + 1]);
+        tB = now();
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    tC = now();
+    if (c->hostBatch.direct ? flagged(0, n) : *(const int*)po != 0) return read_error_flag(c);
+    if (rc) return rc;
+    rc = unpack(0, ngroups > 1 ? gs[1] : n);
+    if (trace)
+        fprintf(stderr, "host batch %d: first of the later groups done at %.0f us, last of them unpacked at %.0f, stream done at %.0f, all unpacked at %.0f\n", n,
+                tA - c->hostBatch.t0, tB - c->hostBatch.t0, tC - c->hostBatch.t0, now() - c->hostBatch.t0);
+    return rc;
+}
+
 extern "C" int orb_extract_batch(orb_ctx* c, const uint8_t* const* imgs, int n, int w, int h, int stride,
                                  orb_keypoint* kps, uint8_t* desc, int cap_per_frame, int* n_out) {
     if (!c || !imgs || !n_out) {
@@ -981,135 +1339,129 @@ extern "C" int orb_extract_batch(orb_ctx* c, const uint8_t* const* imgs, int n, 
         for (int f = 0; f < n; f++) n_out[f] = 0;
         return ORB_OK;
     }
-    if (n < 1 || n > c->prm.max_batch || w > c->prm.max_width || h > c->prm.max_height || stride < w) {
-        orb_set_error("orb_extract_batch: batch %d / frame %dx%d stride %d outside the context's limits", n, w, h,
-                      stride);
-        return ORB_ERR_INVALID;
+    int rc = extract_batch_begin(c, imgs, n, w, h, stride, kps != nullptr, desc != nullptr, -1);
+    if (rc) {
+        // whatever was enqueued before the failure reads the staging blocks: let it finish before they are reused
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        return rc;
     }
-    HIP_TRY(hipSetDevice(c->prm.device));
-    int rc = compute_geom(c, w, h);
-    if (rc) return rc;
-    const int cap = orb_max_keypoints_per_frame(c);
-    const int dstride = c->inputStride;
-    const int64_t fstride = (int64_t)dstride * h;
-    // frames -> page-locked staging in the device layout (row copies on the host) -> device.  A single host thread
-    // copies at a fraction of the link rate, so a batch is staged by up to four threads, slice by slice, and every
-    // slice is handed to the DMA engine as soon as it is staged (host copies and DMA overlap).  The copies go to ONE
-    // stream, in a fixed order (copies on several streams at once share the link badly: 17 instead of 56 GB/s), in
-    // slices of about 5 MB (consecutive copies on a stream leave 18 us between them and cost the enqueuing thread
-    // 15 us each: 1.2 MB slices ran at 35 GB/s; a kernel that reads the staging block over the link itself has no
-    // such gaps but is slower, 0.89 against 0.82 ms for 64 frames).  The frames of
-    // the later frame groups go first and an event marks their arrival: those groups start extracting while the first
-    // group's frames, the last to arrive, are still on the link.
-    if ((rc = c->pinIn.ensure((size_t)n * fstride))) return rc;
+    return extract_batch_finish(c, kps, desc, cap_per_frame, n_out);
+}
+
+// Frame blocks over several contexts (one per device), host pointers.  Page-locked frames: the calling thread
+// enqueues every context's block (copies, kernels, result copy: a fraction of a millisecond of host time each) and
+// then collects them in turn, so the devices work side by side without any thread being made.  Pageable frames have
+// to be copied into staging by the host first, which is the slow part: one host thread per context.
+int orb_extract_batch_over_contexts(orb_ctx* const* ctxs, int nctx, const uint8_t* const* imgs, int n, int w, int h, int stride,
+                                    orb_keypoint* kps, uint8_t* desc, int cap_per_frame, int* n_out) {
+    if (w <= 0 || h <= 0) {
+        for (int f = 0; f < n; f++) n_out[f] = 0;
+        return ORB_OK;
+    }
     for (int f = 0; f < n; f++)
         if (!imgs[f]) {
             orb_set_error("frame %d is null", f);
             return ORB_ERR_INVALID;
         }
-    auto stage_frames = [&](int f0, int f1) {
-        for (int f = f0; f < f1; f++) {
-            uint8_t* dst = (uint8_t*)c->pinIn.p + f * fstride;
-            if (stride == dstride) {
-                memcpy(dst, imgs[f], (size_t)stride * (h - 1) + w);
-            } else {
-                for (int r = 0; r < h; r++) memcpy(dst + (size_t)r * dstride, imgs[f] + (size_t)r * stride, (size_t)w);
+    auto lo = [&](int r) { return (int)((int64_t)n * r / nctx); };
+    auto outK = [&](int f) { return kps ? kps + (size_t)f * cap_per_frame : nullptr; };
+    auto outD = [&](int f) { return desc ? desc + (size_t)f * cap_per_frame * 32 : nullptr; };
+    if (stride >= w && frames_page_locked(imgs, n, (size_t)stride * (h - 1) + w)) {
+        int rc = ORB_OK, begun = 0;
+        for (int r = 0; r < nctx && rc == ORB_OK; r++, begun++)
+            if (lo(r + 1) > lo(r)) rc = extract_batch_begin(ctxs[r], imgs + lo(r), lo(r + 1) - lo(r), w, h, stride, kps != nullptr, desc != nullptr, 1);
+        if (rc != ORB_OK) {  // leave no context with work in flight or a batch open
+            char msg[512];
+            snprintf(msg, sizeof(msg), "%s", orb_last_error());
+            for (int r = 0; r < begun; r++) {
+                (void)hipSetDevice(ctxs[r]->prm.device);
+                if (ctxs[r]->stream) (void)hipStreamSynchronize(ctxs[r]->stream);
+                ctxs[r]->hostBatch.open = false;
             }
+            orb_set_error("%s", msg);
+            return rc;
+        }
+        for (int r = 0; r < nctx; r++) {
+            if (lo(r + 1) == lo(r)) continue;
+            const int rr = extract_batch_finish(ctxs[r], outK(lo(r)), outD(lo(r)), cap_per_frame, n_out + lo(r));
+            if (rr != ORB_OK && rc == ORB_OK) {
+                char msg[400];
+                snprintf(msg, sizeof(msg), "%s", orb_last_error());
+                orb_set_error("frame block %d: %s", r, msg);
+                rc = rr;
+            }
+        }
+        return rc;
+    }
+    std::vector<int> rcs(nctx, ORB_OK);
+    std::vector<std::vector<char> > msgs(nctx);
+    auto work = [&](int r) {
+        if (lo(r + 1) == lo(r)) return;
+        rcs[r] = orb_extract_batch(ctxs[r], imgs + lo(r), lo(r + 1) - lo(r), w, h, stride, outK(lo(r)), outD(lo(r)), cap_per_frame,
+                                   n_out + lo(r));
+        if (rcs[r]) {  // the message is per thread: hand it to the caller's
+            const char* m = orb_last_error();
+            msgs[r].assign(m, m + strlen(m) + 1);
         }
     };
-    const bool few = n < ORB_STAGE_SLICE;
-    static const bool trace = getenv("ORBHIP_HOST_TRACE") != nullptr;
-    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double T0 = now();
-    double T1 = 0, T2 = 0, T3 = 0;
-    hipEvent_t laterIn = nullptr;
-    if (few) {
-        // a few frames (the reference's one-frame-per-call use): one host thread, one copy
-        stage_frames(0, n);
-        HIP_TRY(hipMemcpyAsync(c->dInput.p, c->pinIn.p, (size_t)n * fstride, hipMemcpyHostToDevice, c->stream));
-    } else {
-        const int parts = batch_parts(c, n);
-        const int g1 = parts > 1 ? n / parts : 0;  // frames [g1, n) belong to the later groups
-        const int per = (int)std::max<int64_t>(1, std::min<int64_t>(n, ORB_STAGE_SLICE_BYTES / fstride));
-        int sl0[ORB_MAX_STAGE_SLICES], sl1[ORB_MAX_STAGE_SLICES], nsl = 0, nLater = 0;
-        // (a slice holds at least n / 30 frames: the two runs below, each ending in a shorter slice, make at most 32)
-        const int perCapped = std::max(per, (n + ORB_MAX_STAGE_SLICES / 2 - 3) / (ORB_MAX_STAGE_SLICES / 2 - 2));
-        for (int s0 = g1; s0 < n; s0 += perCapped) sl0[nsl] = s0, sl1[nsl++] = std::min(n, s0 + perCapped);
-        nLater = g1 > 0 ? nsl : 0;
-        for (int s0 = 0; s0 < g1; s0 += perCapped) sl0[nsl] = s0, sl1[nsl++] = std::min(g1, s0 + perCapped);
-        // every slice is staged by all the threads together, a share of its frames each; whoever finishes a slice's
-        // last share hands the slice to the DMA engine.  A thread takes the slices in order, so the last share of
-        // slice k is finished after its owner has enqueued every earlier slice it completed: copies are enqueued
-        // in slice order without any waiting.
-        const int nthreads = std::max(1, std::min(c->stageThreads, n / ORB_STAGE_SLICE));
-        hipError_t terr[ORB_STAGE_THREADS];
-        std::atomic<int> arrived[ORB_MAX_STAGE_SLICES];
-        for (int k = 0; k < nsl; k++) arrived[k].store(0, std::memory_order_relaxed);
-        auto stage = [&](int t) {
-            terr[t] = t ? hipSetDevice(c->prm.device) : hipSuccess;
-            for (int k = 0; k < nsl; k++) {
-                const int m = sl1[k] - sl0[k];
-                stage_frames(sl0[k] + m * t / nthreads, sl0[k] + m * (t + 1) / nthreads);
-                if (arrived[k].fetch_add(1, std::memory_order_acq_rel) + 1 < nthreads || terr[t] != hipSuccess) continue;
-                const size_t off = (size_t)sl0[k] * fstride;
-                terr[t] = hipMemcpyAsync((uint8_t*)c->dInput.p + off, (uint8_t*)c->pinIn.p + off, (size_t)m * fstride,
-                                         hipMemcpyHostToDevice, c->stream);
-                if (terr[t] == hipSuccess && k + 1 == nLater) terr[t] = hipEventRecord(c->evIn, c->stream);
-            }
-        };
-        std::thread workers[ORB_STAGE_THREADS];
-        for (int t = 1; t < nthreads; t++) workers[t] = std::thread(stage, t);
-        stage(0);
-        for (int t = 1; t < nthreads; t++) workers[t].join();
-        for (int t = 0; t < nthreads; t++) HIP_TRY(terr[t]);
-        if (nLater > 0) laterIn = c->evIn;
-    }
-    // results: [flag words | counts | keypoints (cap per frame) | descriptors] as one block.  A batch leaves it in
-    // device memory and fetches it with one copy; a few frames write it straight into the page-locked host block
-    // (the last kernel stores the rows over the link itself: a copy between two kernels and the synchronisation
-    // costs more than the 64 KB per frame take), with the flag word as the last stage saw it per frame.
-    T1 = now();
-    const size_t offCnt = 64, offKps = offCnt + (((size_t)n * 4 + 63) & ~(size_t)63);
-    const size_t offDesc = offKps + (size_t)n * cap * sizeof(orb_keypoint);
-    const size_t total = offDesc + (size_t)n * cap * 32;
-    if ((rc = c->pinOut.ensure(total))) return rc;
-    uint8_t* po = (uint8_t*)c->pinOut.p;
-    static_assert(ORB_STAGE_SLICE * sizeof(int) <= 64, "the per-frame flag words share the block's first 64 bytes");
-    if (few) {
-        uint8_t* dpo = nullptr;  // the block as the device addresses it
-        HIP_TRY(hipHostGetDevicePointer((void**)&dpo, po, 0));
-        rc = run_batch(c, (const uint8_t*)c->dInput.p, n, w, h, dstride, fstride, (orb_keypoint*)(dpo + offKps), dpo + offDesc,
-                       cap, (int*)(dpo + offCnt), c->stream, (int*)dpo);
-        if (rc) return rc;
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        for (int f = 1; f < n; f++) ((int*)po)[0] |= ((const int*)po)[f];
-    } else {
-        uint8_t* dOut = (uint8_t*)c->dHostOut.p;
-        rc = run_batch(c, (const uint8_t*)c->dInput.p, n, w, h, dstride, fstride, (orb_keypoint*)(dOut + offKps), dOut + offDesc,
-                       cap, (int*)(dOut + offCnt), c->stream, nullptr, laterIn);
-        if (rc) return rc;
-        T2 = now();
-        HIP_TRY(hipMemcpyAsync(po, dOut, (kps || desc) ? (desc ? total : offDesc) : offKps, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
-    T3 = now();
-    if (*(const int*)po != 0) return read_error_flag(c);
-    memcpy(n_out, po + offCnt, (size_t)n * 4);
-    for (int f = 0; f < n; f++) {
-        const int m = n_out[f];
-        if (m > cap_per_frame) {
-            orb_set_error("frame %d produced %d keypoints, caller capacity is %d", f, m, cap_per_frame);
-            return ORB_ERR_CAPACITY;
+    std::vector<std::thread> th;
+    for (int r = 1; r < nctx; r++) th.emplace_back(work, r);
+    work(0);
+    for (std::thread& t : th) t.join();
+    for (int r = 0; r < nctx; r++)
+        if (rcs[r]) {
+            orb_set_error("frame block %d: %s", r, msgs[r].data());
+            return rcs[r];
         }
-        if (m > 0) {
-            if (kps)
-                memcpy(kps + (size_t)f * cap_per_frame, po + offKps + (size_t)f * cap * sizeof(orb_keypoint),
-                       (size_t)m * sizeof(orb_keypoint));
-            if (desc) memcpy(desc + (size_t)f * cap_per_frame * 32, po + offDesc + (size_t)f * cap * 32, (size_t)m * 32);
-        }
-    }
-    if (trace) fprintf(stderr, "host batch %d: stage+enqueue %.0f us, launch %.0f us, wait %.0f us, unpack %.0f us (result block %zu bytes)\n", n, T1 - T0, T2 - T1, T3 - T2, now() - T3, total);
     return ORB_OK;
+}
+
+// The same with every block resident on its context's device: one enqueue per context from the calling thread.
+int orb_extract_batch_over_contexts_device(orb_ctx* const* ctxs, int nctx, const uint8_t* const* d_imgs, int n, int w, int h,
+                                           int stride, int64_t frame_stride, orb_keypoint* const* d_kps, uint8_t* const* d_desc,
+                                           int cap_per_frame, int* const* d_n_out, void* const* streams) {
+    for (int r = 0; r < nctx; r++) {
+        const int f0 = (int)((int64_t)n * r / nctx), f1 = (int)((int64_t)n * (r + 1) / nctx);
+        if (f1 == f0) continue;
+        if (!d_imgs[r] || !d_kps[r] || !d_desc[r] || !d_n_out[r]) {
+            orb_set_error("orb_extract_batch_multi_device: block %d has a null buffer", r);
+            return ORB_ERR_INVALID;
+        }
+        const int rc = run_batch(ctxs[r], d_imgs[r], f1 - f0, w, h, stride, frame_stride, d_kps[r], d_desc[r], cap_per_frame,
+                                 d_n_out[r], streams ? (hipStream_t)streams[r] : ctxs[r]->stream);
+        if (rc) {
+            char msg[400];
+            snprintf(msg, sizeof(msg), "%s", orb_last_error());
+            orb_set_error("frame block %d: %s", r, msg);
+            return rc;
+        }
+    }
+    if (!streams)  // the contexts' own streams: the call is complete when it returns
+        for (int r = 0; r < nctx; r++) {
+            HIP_TRY(hipSetDevice(ctxs[r]->prm.device));
+            HIP_TRY(hipStreamSynchronize(ctxs[r]->stream));
+        }
+    return ORB_OK;
+}
+
+// Page-locked host memory for callers that do not link the HIP runtime themselves: frames read into such a block
+// (or any memory registered with hipHostRegister) reach the device without a staging copy.
+extern "C" int orb_alloc_host(size_t bytes, void** out) {
+    if (!out || bytes == 0) {
+        orb_set_error("orb_alloc_host: bad arguments");
+        return ORB_ERR_INVALID;
+    }
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocPortable);
+    if (e != hipSuccess) {
+        *out = nullptr;
+        orb_set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return ORB_ERR_NOMEM;
+    }
+    return ORB_OK;
+}
+extern "C" void orb_free_host(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 extern "C" int orb_extract(orb_ctx* c, const uint8_t* img, int w, int h, int stride, orb_keypoint* kps, uint8_t* desc,
