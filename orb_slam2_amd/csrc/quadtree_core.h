@@ -370,6 +370,9 @@ struct QtSortedSpace {
         qt_children(s, nd, b, err);
     }
     QT_MFN int child_b0(const OrbNode&, int) const { return 0; }
+    QT_MFN int jump_depth() const { return 0; }  // (no shortcut over the first coarse passes in this form)
+    QT_MFN int count_at(int, int) const { return 0; }
+    QT_MFN int cell_lo(int, int) const { return 0; }
     QT_MFN int items(const OrbNode& nd) const { return nd.hi - nd.lo; }
     QT_MFN uint32_t prio_at(const OrbNode& nd, int i) const { return qt_entry_prio(s[nd.lo + i]); }
 };
@@ -423,6 +426,11 @@ struct QtHistSpace {
         const int d = QT_DEPTH(nd);
         return d < Db ? QT_B0(nd) + q * (1 << (2 * (Db - d - 1))) : QT_B0(nd);
     }
+    // Every quadtree cell down to the bucket depth is a difference of two entries of start[]: the first coarse
+    // passes can be evaluated from the counts alone (qt_jump).
+    QT_MFN int jump_depth() const { return Db; }
+    QT_MFN int cell_lo(int d, int c) const { return start[c << (2 * (Db - d))]; }
+    QT_MFN int count_at(int d, int c) const { return start[(c + 1) << (2 * (Db - d))] - start[c << (2 * (Db - d))]; }
     QT_MFN int items(const OrbNode& nd) const {
         const int d = QT_DEPTH(nd);
         return d < Db ? 1 << (2 * (Db - d)) : 1;
@@ -474,6 +482,185 @@ QT_FN void qt_emit_children(const Space& sp, const OrbNode& nd, const int* b, Or
     }
 }
 
+// ---- the first coarse passes in one step ------------------------------------------------------------------
+// While a coarse pass neither ends the distribution nor hands over to the fine phase, the next pass divides
+// every divisible node again (src/ORBextractor.cc:625-701), so what the list looks like after K such passes does
+// not depend on the lists in between:
+//  * it holds the non-empty quadtree cells of depth K all of whose ancestors were divisible, followed by the
+//    cells of depth K - 1, K - 2, .. 0 that stopped being divisible there (one key; with the fork's rule every
+//    n3), ancestors divisible likewise;
+//  * a pass puts the children of the LAST divisible node first and n4 before n1, and moves what stays behind them
+//    in the old order; so the cells of one depth d stand in the order of their paths with digit j (1 .. d)
+//    descending when d - j is even, ascending when it is odd, and the initial node descending when d is odd;
+//  * whether pass p is the last one follows from three counts per depth: cells of the list's front block T[p],
+//    those of them with several keys E[p] (what the fine phase would divide), and those that stop D[p]:
+//    the list holds T[p] + D[0] + .. + D[p - 1] nodes after pass p.
+// qt_jump classifies every cell of depths 0 .. Dj at once (a cell's count is a difference of two prefix sums;
+// its ancestors are a few more), finds K from the counts, and writes the list after pass K with one prefix sum.
+// Creation numbers: the front block's, which the fine phase orders by, are exact; cells of the tail (which are
+// never divided again) get -1.
+#define QT_JUMP_MAX 12  // deepest pass the shortcut evaluates (bounded by the scratch below and the bucket depth)
+#ifdef ORB_HOST_EMU
+static int g_qtJumpStats[QT_JUMP_MAX + 4];  // tests: how often the shortcut ended in a finish [0], the fine phase [1], another coarse pass [2]; by K from [3]
+#endif
+// The three counts of a depth travel as one 64-bit word (21 bits each), so that a cell adds itself with one atomic.
+#define QT_AGG_T(v) ((int)((v) & 0x1fffffull))
+#define QT_AGG_E(v) ((int)(((v) >> 21) & 0x1fffffull))
+#define QT_AGG_D(v) ((int)((v) >> 42))
+// bits of a cell's class
+#define QT_C_EXISTS 1
+#define QT_C_LIVE 2
+#define QT_C_MULTI 4
+
+template <class Space>
+QT_FN int qt_cell_class(const Space& sp, int d, int c, int n3quirk) {
+    const int cnt = sp.count_at(d, c);
+    // every ancestor divisible?  (depth 0: more than one key; below: the child's flag, qt_child_flags.)  No early
+    // exit: the loads of all ancestors are independent of each other and go out together.
+    bool ok = cnt > 0;
+    for (int a = d - 1; a >= 0; a--) {
+        const int ca = c >> (2 * (d - a));
+        const int q = ca & 3;
+        const bool several = sp.count_at(a, ca) > 1;
+        const bool byQuadrant = a > 0 && n3quirk && q >= 2;  // n4 never stops, n3 always does
+        ok = ok && (byQuadrant ? q == 3 : several);
+    }
+    const int q = c & 3;
+    const bool live = (d > 0 && n3quirk && q >= 2) ? q == 3 : cnt > 1;
+    return ok ? (QT_C_EXISTS | (cnt > 1 ? QT_C_MULTI : 0) | (live ? QT_C_LIVE : 0)) : 0;
+}
+
+// natural cell number of entry t of depth d's block (the order the list keeps a depth's cells in, see above)
+QT_FN int qt_jump_cell(int d, int t, int nIni) {
+    const int low = (1 << (2 * d)) - 1;
+    const int ini = t >> (2 * d);
+    return (((d & 1) ? nIni - 1 - ini : ini) << (2 * d)) | ((t & low) ^ (0x33333333 & low));
+}
+
+// Returns 0 when the shortcut does not apply (the caller starts with an ordinary coarse pass); otherwise the list
+// after pass K is in `cur`, the recorded nodes in w.rec and sh->nL / nRec / seqCounter / fine / finish are as that
+// pass leaves them.
+template <class Space>
+QT_FN int qt_jump(const Space& sp, const QtWork& w, int nIni, int N, int n3quirk, QtShared* sh, OrbNode* cur) {
+    const int T = QT_NT, t = QT_TID;
+    // depths 0 .. Dj: as far as the passes can go before the list reaches the quota by cell count alone, the
+    // bucket depth, and what the scratch (bounds + scanA + scanB + scanC: 7 nodeCap + 3 ints) holds
+    int Dj = 0;
+    while (((long long)nIni << (2 * Dj)) < N && Dj < QT_JUMP_MAX) Dj++;
+    if (Dj > sp.jump_depth()) Dj = sp.jump_depth();
+    int* const F = w.bounds;
+    const long long room = 7ll * w.nodeCap + 3;
+    while (Dj >= 1 && ((((long long)nIni << (2 * (Dj + 1))) - nIni) / 3 + 1) > room) Dj--;  // nIni (4^(Dj+1) - 1) / 3 cells + 1
+    if (Dj < 1) return 0;
+    // the cells of depth d are a block of nIni 4^d entries, deepest depth first, as the list has them
+    const int M = (int)((((long long)nIni << (2 * (Dj + 1))) - nIni) / 3);
+    auto locate = [&](int i, int* depth, int* entry) {  // flat index -> (depth, entry of the depth's block)
+        int d = Dj, o = 0, sz = nIni << (2 * Dj);
+        while (d > 0 && i >= o + sz) {
+            o += sz;
+            sz >>= 2;
+            d--;
+        }
+        *depth = d;
+        *entry = i - o;
+    };
+    unsigned long long* const agg = (unsigned long long*)sh->bigList;  // per depth: T | E << 21 | D << 42
+    static_assert(QT_BIG_LIST * sizeof(int) >= (QT_JUMP_MAX + 1) * sizeof(unsigned long long), "per-depth counters live in bigList");
+    for (int i = t; i <= Dj; i += T) agg[i] = 0ull;
+    QT_BARRIER();
+    for (int base = 0; base < M; base += T) {
+        const int i = base + t;
+        int d, e;
+        locate(i < M ? i : M - 1, &d, &e);
+        const bool in = i < M;
+        const int cls = in ? qt_cell_class(sp, d, qt_jump_cell(d, e, nIni), n3quirk) : 0;
+        if (in) F[i] = cls | (d << 8);
+        const unsigned long long add = (cls & QT_C_EXISTS) ? 1ull | ((cls & QT_C_MULTI) ? 1ull << 21 : 0ull) | ((cls & QT_C_LIVE) ? 0ull : 1ull << 42) : 0ull;
+#ifdef ORB_HOST_EMU
+        agg[d] += add;
+#else
+        // a wavefront whose cells all lie at one depth (most do) adds its three counts with one atomic
+        const int d0 = __builtin_amdgcn_readfirstlane(d);
+        if (__all(d == d0)) {
+            const unsigned long long mT = __ballot((cls & QT_C_EXISTS) != 0), mE = __ballot((cls & QT_C_EXISTS) && (cls & QT_C_MULTI)),
+                                     mD = __ballot((cls & QT_C_EXISTS) && !(cls & QT_C_LIVE));
+            if ((t & 63) == 0 && mT)
+                atomicAdd(&agg[d0], (unsigned long long)__popcll(mT) | ((unsigned long long)__popcll(mE) << 21) | ((unsigned long long)__popcll(mD) << 42));
+        } else if (add) {
+            atomicAdd(&agg[d], add);
+        }
+#endif
+    }
+    QT_BARRIER();
+    QT_STAMP(13);
+    // which pass is the last of the run (every thread finds the same answer)
+    int K = 1, size = 0, prev = QT_AGG_T(agg[0]), tail = QT_AGG_D(agg[0]), fine = 0, finish = 0, seqNext = nIni, nRec = 0;
+    for (int p = 1;; p++) {
+        const unsigned long long ap = agg[p];
+        size = QT_AGG_T(ap) + tail;
+        seqNext += QT_AGG_T(ap);
+        nRec = QT_AGG_E(ap);
+        finish = size >= N || size == prev;
+        fine = !finish && size + 3 * nRec > N;
+        K = p;
+        if (finish || fine || p == Dj) break;
+        tail += QT_AGG_D(ap);
+        prev = size;
+    }
+#ifdef ORB_HOST_EMU
+    g_qtJumpStats[finish ? 0 : fine ? 1 : 2]++;
+    g_qtJumpStats[3 + K]++;
+#endif
+    // list positions: front block, then the stopped cells of the shallower depths; recorded nodes counted alongside
+    for (int i = t; i < M; i += T) {
+        const int v = F[i], d = v >> 8, cls = v & 255;
+        int f = 0;
+        if (cls & QT_C_EXISTS) {
+            if (d == K) f = 1 | ((cls & QT_C_MULTI) ? 1 << 16 : 0);
+            else if (d < K && !(cls & QT_C_LIVE)) f = 1;
+        }
+        F[i] = f;
+    }
+    QT_BARRIER();
+    qt_scan(F, M, sh);
+    QT_STAMP(14);
+    if (size > w.nodeCap) {  // cannot happen by the size bound; fail loudly
+        if (t == 0) { sh->err = 2; sh->finish = 1; sh->nL = 0; }
+        QT_BARRIER();
+        return 1;
+    }
+    for (int i = t; i < M; i += T) {
+        const int a = F[i], f = F[i + 1] - a;
+        if (!(f & 0xffff)) continue;
+        int d, e;
+        locate(i, &d, &e);
+        const int pos = a & 0xffff, c = qt_jump_cell(d, e, nIni);
+        const int cnt = sp.count_at(d, c), q = c & 3;
+        OrbNode nd;
+        nd.lo = sp.cell_lo(d, c);
+        nd.hi = nd.lo + cnt;
+        const int flags = d == 0 ? (cnt == 1 ? QT_NOMORE : 0) : qt_child_flags(q, cnt, n3quirk);
+        nd.depthFlags = d | flags | ((c << (2 * (sp.jump_depth() - d))) << QT_B0_SHIFT);
+        nd.seq = d == K ? seqNext - 1 - pos : -1;  // created in the reverse of the list order, numbers ending at seqNext - 1
+        cur[pos] = nd;
+        if (f >> 16) w.rec[a >> 16] = pos;
+    }
+    if (t == 0) {
+        sh->prevSize = prev;
+        sh->nL = size;
+        sh->nRec = nRec;
+        sh->seqCounter = seqNext;
+        sh->fine = fine;
+        sh->finish = finish;
+    }
+    QT_BARRIER();
+    QT_STAMP(15);
+#if defined(QT_PROFILE) && !defined(ORB_HOST_EMU)
+    if (blockIdx.x == 0 && threadIdx.x == 0) g_qtProfile[30] = (unsigned long long)K, g_qtProfile[31] = (unsigned long long)M;
+#endif
+    return 1;
+}
+
 // Runs the distribution over the keys of `sp`.  On return *outCount nodes are in `*outList` in list order;
 // sh->deeper != 0 means the histogram form could not follow the reference any further (the list is then void).
 template <class Space>
@@ -505,7 +692,15 @@ QT_FN void qt_distribute(const Space& sp, const QtWork& w, int nIni, int N, int 
     }
     QT_BARRIER();
 
+    // the run of coarse passes that neither finish nor hand over to the fine phase, in one step where the key
+    // space allows it; the loop below then starts behind the coarse pass
+    int jumped = 0;
+#ifndef QT_NO_JUMP
+    if (sp.jump_depth() > 0) jumped = qt_jump(sp, w, nIni, N, n3quirk, sh, cur);
+#endif
+
     while (!sh->finish) {
+      if (!jumped) {
         // ---- coarse pass, src/ORBextractor.cc:625-697 ------------------------------
         QT_COUNT(16);
 #if defined(QT_PROFILE) && !defined(ORB_HOST_EMU)
@@ -566,6 +761,8 @@ QT_FN void qt_distribute(const Space& sp, const QtWork& w, int nIni, int N, int 
         }
         { OrbNode* tmp = cur; cur = nxt; nxt = tmp; }
         QT_BARRIER();
+      }
+        jumped = 0;
 
         // ---- fine phase, src/ORBextractor.cc:702-770 ------------------------------
         while (sh->fine && !sh->finish) {

@@ -80,3 +80,9 @@ extern "C" int qt_emu_distribute_hist(const int* xs, const int* ys, const int* s
 // Bucket depth the device uses for a level: two digits below the depth at which the initial nodes' descendants
 // can first reach the quota, as far as `bucketCap` buckets allow (orb_api.hip computes the same).
 extern "C" int qt_emu_hist_depth(int nIni, int N, int bucketCap) { return qt_hist_depth(nIni, N, bucketCap); }
+
+// How often the shortcut over the first coarse passes ran and how it ended: out[0] finished, out[1] fine phase next,
+// out[2] another coarse pass next, out[3 + K] runs that covered K passes.
+extern "C" void qt_emu_jump_stats(int* out, int n) {
+    for (int i = 0; i < n && i < QT_JUMP_MAX + 4; i++) out[i] = g_qtJumpStats[i];
+}

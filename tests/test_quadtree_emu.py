@@ -132,3 +132,16 @@ def test_emu_matches_oracle_on_random_keys(emu, oracle, quirk):
         check(emu, oracle, e, keys, 16, 16 + w, 16, 16 + h, N, quirk)
     emu.qt_emu_set_bin_bits(12)
     assert 0 < HIST["deeper"] < HIST["runs"]  # both outcomes of the histogram form occurred
+
+
+def test_the_shortcut_over_the_first_coarse_passes_ran(emu, oracle):
+    """The histogram form evaluates the run of coarse passes that neither finish nor start the fine phase from the
+    bucket counts alone (qt_jump).  The tests above compared its lists with the oracle's; this one makes sure they
+    went through the shortcut, with every way it can end and over several depths."""
+    test_emu_matches_oracle_on_random_keys(emu, oracle, True)  # (also when this test runs alone)
+    st = np.zeros(16, dtype=np.int32)
+    emu.qt_emu_jump_stats(st.ctypes.data_as(C.c_void_p), len(st))
+    finished, fine, coarse = (int(v) for v in st[:3])
+    assert finished > 0 and fine > 0 and coarse > 0, st
+    by_k = st[3:]
+    assert by_k[1] > 0 and by_k[2] > 0 and by_k[3] > 0 and by_k[4] > 0, st

@@ -34,4 +34,7 @@ for (w, h, nf, batch, cfg) in [(640, 480, 1000, 1, 1), (640, 480, 1000, 64, 1), 
     print("   distribute: coarse passes start at " + ", ".join("%.1f" % ((x - t0) / 100.0) for x in v[20:26] if x) +
           " us; fine rounds at " + ", ".join("%.1f" % ((x - t0) / 100.0) for x in v[26:30] if x) +
           " us (recorded nodes %d, list %d); end %.1f us" % (v[11], v[12], (v[5] - t0) / 100.0))
+    if v[15]:
+        print("   shortcut over the first %d coarse passes (%d cells looked at): classified at %.1f us, positions at %.1f, list written at %.1f"
+              % (v[30], v[31], (v[13] - t0) / 100.0, (v[14] - t0) / 100.0, (v[15] - t0) / 100.0))
     ctx.close()
