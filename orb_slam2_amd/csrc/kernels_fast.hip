@@ -23,6 +23,24 @@
 
 #include "orb_internal.h"
 
+// Development aid: with -DFAST_PROFILE every cell adds what it did to a table per level (cells, interior pixels,
+// pixels that passed the candidate test, score_chunk calls, corners, keys kept, cells that went to the second
+// attempt, candidates of second attempts), read back with orb_debug_fast_profile (tools/fast_chunk_fill.py).
+#ifdef FAST_PROFILE
+__device__ unsigned long long g_fastProfile[ORB_MAX_LEVELS][8];
+extern "C" int orb_debug_fast_profile(unsigned long long* out, int clear) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fastProfile), sizeof(unsigned long long) * ORB_MAX_LEVELS * 8) != hipSuccess) return -1;
+    if (clear) {
+        static unsigned long long z[ORB_MAX_LEVELS * 8];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_fastProfile), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define FAST_PROF(x) x
+#else
+#define FAST_PROF(x)
+#endif
+
 #define FAST_WAVES 1  // wavefronts per workgroup; with one, a cell's LDS is free again as soon as its wavefront ends
 // LDS geometry per wavefront, a template parameter of the kernel: the pixel tile holds the cell interior
 // plus a 3-pixel halo (plus up to 3 bytes of alignment slack per row and one spare row that the
@@ -280,6 +298,7 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
     uint32_t* out = cellKeys + cellGlobal * cellCap;
     const bool xin = lx < cw;
     int total = 0;
+    FAST_PROF(int profCand = 0; int profChunks = 0; int profCorn = 0; int profSecond = 0; int profCand2 = 0;)
     for (int attempt = 0; attempt < 2; attempt++) {
         const int th = attempt == 0 ? iniTh : minTh;
         int head = 0, tail = 0;  // wave-uniform ring positions, tail - head <= 127
@@ -303,6 +322,7 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
             }
             nCorn += __popcll(m);
             head += count;
+            FAST_PROF(profChunks++; profCorn += __popcll(m); if (attempt) profCand2 += count; else profCand += count;)
         };
         {
             // An adjacent compass pair darker than v - th:  max(min(S,N), min(E,W)) < v - th; one brighter than
@@ -354,6 +374,7 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
             keep |= (unsigned long long)lm << p;
             total += __popcll(__ballot(lm));
         }
+        FAST_PROF(if (total == 0 && attempt == 0 && minTh < iniTh) profSecond = 1;)
         if (total == 0 && attempt == 0 && minTh < iniTh) continue;  // nothing kept: lower threshold, :852-858
         int run = 0;
         for (int p = 0; p < rounds; p++) {
@@ -375,6 +396,19 @@ __attribute__((amdgpu_waves_per_eu(TG::WAVES_PER_SIMD, TG::WAVES_PER_SIMD))) voi
         break;
     }
     if (lane == 0) cellCount[cellGlobal] = total;  // total <= cellCap by the 2x2-block bound on strict local maxima
+#ifdef FAST_PROFILE
+    if (lane == 0) {
+        unsigned long long* pr = g_fastProfile[level];
+        atomicAdd(&pr[0], 1ull);
+        atomicAdd(&pr[1], (unsigned long long)(cw * ch));
+        atomicAdd(&pr[2], (unsigned long long)profCand);
+        atomicAdd(&pr[3], (unsigned long long)profChunks);
+        atomicAdd(&pr[4], (unsigned long long)profCorn);
+        atomicAdd(&pr[5], (unsigned long long)total);
+        atomicAdd(&pr[6], (unsigned long long)profSecond);
+        atomicAdd(&pr[7], (unsigned long long)profCand2);
+    }
+#endif
 }
 
 int orb_launch_fast(const OrbBatch& b) {

@@ -104,10 +104,12 @@ static __device__ __forceinline__ uint32_t list_entry(const MatchBuffers& B, con
 }
 
 // Kernel 1.  Bucket assignment as the Frame constructor does it (PosInGrid): rounded position,
-// keypoints that fall outside the grid are left out.
+// keypoints that fall outside the grid are left out.  maxOctave >= 0 also leaves out the keypoints of coarser
+// levels: a search whose every query asks for levels up to maxOctave only (SearchForInitialization: level 0,
+// src/ORBmatcher.cc:41-46) never looks at them, and a 2000-feature frame has 434 keypoints on level 0.
 __global__ __launch_bounds__(256) void k_grid_build(const orb_keypoint* __restrict__ k2all, const int* __restrict__ n2s,
                                                     int n2const, int stride2, GridGeom G, MatchBuffers B,
-                                                    int* __restrict__ error) {
+                                                    int* __restrict__ error, int maxOctave) {
     __shared__ uint32_t s_sorted[M_MAXKP];
     __shared__ uint32_t s_key[M_MAXKP];
     __shared__ int s_start[M_CELLS + 1];
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void k_grid_build(const orb_keypoint* __restri
         const int px = (int)roundf(__fmul_rn(__fsub_rn(k2[i].x, G.minX), G.wInv));  // Frame::PosInGrid
         const int py = (int)roundf(__fmul_rn(__fsub_rn(k2[i].y, G.minY), G.hInv));
         uint32_t key = 0xFFFFFFFFu;
-        if (px >= 0 && px < ORB_GRID_COLS && py >= 0 && py < ORB_GRID_ROWS) {
+        if (px >= 0 && px < ORB_GRID_COLS && py >= 0 && py < ORB_GRID_ROWS && (maxOctave < 0 || k2[i].octave <= maxOctave)) {
             key = ((uint32_t)(px * ORB_GRID_ROWS + py) << 16) | (uint32_t)i;
             atomicAdd(&s_start[px * ORB_GRID_ROWS + py], 1);
         }
@@ -660,6 +662,277 @@ __global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __res
     if (t == 0) nmatchesOut[pair] = S.cut ? -1 : nmatches;
 }
 
+// Kernel 3 for the window search (SearchForInitialization), 64 queries at a time.
+//
+// Queries interact only through the keypoints they are matched to: an acceptance lowers vMatchedDistance of one
+// keypoint (src/ORBmatcher.cc:63-64, 89), which hides that keypoint from later queries whose distance to it is
+// not smaller.  The next 64 queries with candidates (a "run") are resolved together, four lanes per query, by
+// iteration: every query is evaluated against the state the runs before left AND the claims the earlier queries
+// of its own run made in the previous round (a claim = "query a accepts keypoint p at distance d"; what a later
+// query k sees of p is the claim of the last claimer before k, exactly what vMatchedDistance would hold when the
+// walk in order reaches k); queries whose outcome changed post their new claim, and the rounds go on until
+// nothing changes.  Query 0 of the run sees no claims and is final after round 1, query 1 after round 2 at the
+// latest, and so on: the iteration ends, in at most 65 rounds, at the outcome of the walk in order (its only fixed
+// point).  On ordinary frames three to five rounds do.  Then the run is committed: state per keypoint, by sorted
+// position, is distance << 16 | owner, so that an atomic minimum keeps the latest (smallest) accepted distance.
+// The lists of the next run are fetched while the rounds of the current one go on.  Everything after the walk
+// (vnMatches12 from the final owners, rotation histogram over all acceptances, three maxima, removal,
+// vbPrevMatched) is as in k_match_resolve<0>.
+#define M_RUN 64            // queries resolved together
+#define M_PAR_MAXKP 4096    // keypoints of the searched frame, and queries with candidates, this kernel's LDS holds
+#define M_TILE_W 128        // list entries per query held in LDS (the rest is read from the list itself)
+#define M_TILE_PITCH 129
+#define M_PAR_THREADS 1024  // sixteen lanes per query of a run
+struct ResolveParLds {
+    unsigned long long claims[M_PAR_MAXKP];  // by sorted position: bit k = query k of the run claims the keypoint
+    uint32_t so[M_PAR_MAXKP];                // vMatchedDistance << 16 | vnMatches21 (0xFFFFFFFF: INT_MAX, -1)
+    uint16_t idx[M_PAR_MAXKP];               // keypoint index by sorted position
+    uint16_t qI1[M_PAR_MAXKP], qCnt[M_PAR_MAXKP];  // the queries with candidates, in order: index, list length
+    uint32_t tile[2][M_RUN * M_TILE_PITCH];  // first entries of the run's lists, double buffered
+    uint32_t k1[M_RUN];                      // a query's outcome of the previous round: best key, 0xFFFFFFFF = no acceptance
+    int hist[ORB_HISTO + 1];
+    int wcount[M_PAR_THREADS / 64];
+    int changed[2];
+    int nmatches, cut;
+};
+
+__global__ __launch_bounds__(M_PAR_THREADS) void k_match_resolve_window(const orb_keypoint* __restrict__ k1all,
+                                                              const int* __restrict__ n1s, int stride1,
+                                                              const orb_keypoint* __restrict__ k2all,
+                                                              const int* __restrict__ n2s, int stride2,
+                                                              float* __restrict__ prevAll, int* __restrict__ m12All,
+                                                              uint8_t* __restrict__ binOfAll, float nnratio, int checkOri,
+                                                              MatchBuffers B, int* __restrict__ nmatchesOut,
+                                                              int* __restrict__ error) {
+    __shared__ ResolveParLds S;
+#ifdef MATCH_PROFILE
+    const unsigned long long profT0 = wall_clock64();
+#endif
+    const int pair = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const orb_keypoint* k1 = k1all + (int64_t)pair * stride1;
+    const orb_keypoint* k2 = k2all + (int64_t)pair * stride2;
+    float* prev = prevAll + (int64_t)pair * stride1 * 2;
+    int* m12 = m12All + (int64_t)pair * stride1;
+    uint8_t* binOf = binOfAll + (int64_t)pair * stride1;
+    const int* counts = B.counts + (int64_t)pair * stride1;
+    int* accepted = B.accepted + (int64_t)pair * stride1;
+    const uint32_t* lists = B.lists + (int64_t)pair * stride1 * B.capQ;
+    const int* cellStart = B.cellStart + (int64_t)pair * (M_CELLS + 1);
+    const uint32_t* gS = B.gSorted + (int64_t)pair * stride2;
+    const int nq = n1s[pair], n2 = n2s[pair];
+    if (nq > stride1 || nq > M_PAR_MAXKP || n2 > stride2 || n2 > M_PAR_MAXKP) {  // (the host picks this kernel by the strides)
+        if (t == 0) {
+            atomicOr(error, M_ERR_LIMIT);
+            nmatchesOut[pair] = 0;
+        }
+        return;
+    }
+    const int nIn = cellStart[M_CELLS];
+    for (int i = t; i < nq; i += M_PAR_THREADS) {
+        m12[i] = -1;
+        binOf[i] = 0xFF;
+        accepted[i] = -1;
+    }
+    for (int p = t; p < nIn; p += M_PAR_THREADS) {
+        S.idx[p] = (uint16_t)(gS[p] & 0xFFFFu);
+        S.so[p] = 0xFFFFFFFFu;
+        S.claims[p] = 0ull;
+    }
+    if (t <= ORB_HISTO) S.hist[t] = 0;
+    if (t == 0) {
+        S.nmatches = 0;
+        S.cut = 0;
+        S.changed[0] = S.changed[1] = 0;
+    }
+    __syncthreads();
+
+    // queries with a non-empty list, in index order (the others cannot match and change nothing)
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int nActive = 0;
+    for (int b0 = 0; b0 < nq; b0 += M_PAR_THREADS) {
+        const int i = b0 + t;
+        const int cnt = i < nq ? counts[i] : 0;
+        const bool act = cnt > 0;
+        if (act && B.ovfStart[(int64_t)pair * stride1 + i] < 0) S.cut = 1;
+        const unsigned long long m = __ballot(act);
+        if (lane == 0) S.wcount[wave] = __popcll(m);
+        __syncthreads();
+        int off = nActive;
+        int all = 0;
+        for (int w2 = 0; w2 < M_PAR_THREADS / 64; w2++) {
+            if (w2 < wave) off += S.wcount[w2];
+            all += S.wcount[w2];
+        }
+        if (act) {
+            const int slot = off + __popcll(m & below);
+            S.qI1[slot] = (uint16_t)i;
+            S.qCnt[slot] = (uint16_t)(cnt < 0xFFFF ? cnt : 0xFFFF);
+        }
+        nActive += all;
+        __syncthreads();
+    }
+
+    // the lists of a run -> one half of the tile: thread = (query t / 16, every sixteenth entry); sixteen lanes, one
+    // DPP row, per query, and four wavefronts per SIMD to cover each other's LDS round trips
+    const int kq = t >> 4, sub = t & 15;
+    uint32_t held[M_TILE_W / 16];
+    auto fetch = [&](int base) {
+        const int a = base + kq;
+        const bool in = a < nActive;
+        const int cnt = in ? (int)S.qCnt[a] : 0;
+        const uint32_t* seg = lists + (int64_t)(in ? (int)S.qI1[a] : 0) * B.capQ;
+#pragma unroll
+        for (int j = 0; j < M_TILE_W / 16; j++) {
+            const int c = sub + 16 * j;
+            held[j] = (c < cnt && c < B.capQ) ? seg[c] : 0xFFFFFFFFu;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < M_TILE_W / 16; j++) S.tile[buf][kq * M_TILE_PITCH + sub + 16 * j] = held[j];
+    };
+    if (nActive > 0) {
+        fetch(0);
+        stash(0);
+    }
+    __syncthreads();
+
+#ifdef MATCH_PROFILE
+    int profRounds = 0;
+    const unsigned long long profT1 = wall_clock64();
+#endif
+    int flip = 0;  // which of the two `changed` words the current round uses
+    for (int base = 0, buf = 0; base < nActive; base += M_RUN, buf ^= 1) {
+        const int a = base + kq;
+        const bool in = a < nActive;
+        const int i1 = in ? (int)S.qI1[a] : 0;
+        int cnt = in ? (int)S.qCnt[a] : 0;
+        if (cnt == 0xFFFF) cnt = counts[i1];
+        if (base + M_RUN < nActive) fetch(base + M_RUN);  // in flight during the rounds below
+        const uint32_t* row = &S.tile[buf][kq * M_TILE_PITCH];
+        const uint32_t* seg = lists + (int64_t)i1 * B.capQ;
+        const int ovf = (in && cnt > M_TILE_W) ? B.ovfStart[(int64_t)pair * stride1 + i1] : 0;
+        const unsigned long long earlier = kq == 0 ? 0ull : (~0ull >> (64 - kq));
+        if (sub == 15) S.k1[kq] = 0xFFFFFFFFu;
+        uint32_t mine = 0xFFFFFFFFu;  // this query's claim as posted (best key when accepted)
+        __syncthreads();
+        for (int round = 0;; round++) {
+            // evaluate against the committed state and the earlier queries' claims of the previous round
+            uint32_t a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu;
+            auto consider = [&](uint32_t e) {
+                const uint32_t p = e & 0xFFFFu, d = e >> 16;
+                bool hidden = (S.so[p] >> 16) <= d;  // :63-64
+                const unsigned long long m = S.claims[p] & earlier;
+                if (m) hidden = hidden || (S.k1[63 - __clzll(m)] >> 16) <= d;  // the last claimer before this query
+                if (!hidden) {
+                    a2 = min(a2, max(a1, e));
+                    a1 = min(a1, e);
+                }
+            };
+            const int inTile = cnt < M_TILE_W ? cnt : M_TILE_W;
+            for (int c = sub; c < inTile; c += 16) consider(row[c]);
+            for (int c = M_TILE_W + sub; c < cnt; c += 16) consider(list_entry(B, seg, ovf, c));
+            dpp_top2_step<0x111, 0xf>(a1, a2);
+            dpp_top2_step<0x112, 0xf>(a1, a2);
+            dpp_top2_step<0x114, 0xf>(a1, a2);
+            dpp_top2_step<0x118, 0xf>(a1, a2);  // lane 15 of the row holds the query's two smallest keys
+            uint32_t now = 0xFFFFFFFFu;
+            if (a1 != 0xFFFFFFFFu) {
+                const int bestDist = (int)(a1 >> 16);
+                const float bestDist2 = (a2 == 0xFFFFFFFFu) ? (float)INT_MAX : (float)(int)(a2 >> 16);
+                if (bestDist <= M_TH_LOW && (float)bestDist < __fmul_rn(bestDist2, nnratio)) now = a1;  // :78-80
+            }
+            __syncthreads();  // every query has read the claims of the previous round
+            if (sub == 15 && in && now != mine) {
+                if (mine != 0xFFFFFFFFu) atomicAnd(&S.claims[mine & 0xFFFFu], ~(1ull << kq));
+                if (now != 0xFFFFFFFFu) atomicOr(&S.claims[now & 0xFFFFu], 1ull << kq);
+                S.k1[kq] = now;
+                S.changed[flip] = 1;
+            }
+            mine = now;
+            if (t == 0) S.changed[flip ^ 1] = 0;
+            __syncthreads();
+            const int again = S.changed[flip];
+            flip ^= 1;
+#ifdef MATCH_PROFILE
+            profRounds++;
+#endif
+            if (!again) break;
+        }
+        // commit the run; take its claims back
+        if (sub == 15 && in && mine != 0xFFFFFFFFu) {
+            const uint32_t pos = mine & 0xFFFFu;
+            atomicMin(&S.so[pos], ((mine >> 16) << 16) | (uint32_t)i1);
+            accepted[i1] = (int)S.idx[pos];
+            S.claims[pos] = 0ull;
+        }
+        if (base + M_RUN < nActive) stash(buf ^ 1);
+        __syncthreads();
+    }
+#ifdef MATCH_PROFILE
+    const unsigned long long profT2 = wall_clock64();
+#endif
+    // vnMatches12: query i1 holds keypoint i2 exactly when i2's owner is i1 at the end, a stolen match having
+    // lost its owner (:82-86)
+    __threadfence_block();
+    __syncthreads();
+    {
+        int mine = 0;
+        for (int p = t; p < nIn; p += M_PAR_THREADS) {
+            const uint32_t v = S.so[p];
+            if (v == 0xFFFFFFFFu) continue;
+            m12[v & 0xFFFFu] = S.idx[p];
+            mine++;
+        }
+        if (mine) atomicAdd(&S.nmatches, mine);
+    }
+    __threadfence_block();
+    __syncthreads();
+    int nmatches = S.nmatches;
+    if (checkOri) {  // :88-99 after the fact: one histogram entry per acceptance
+        for (int i = t; i < nq; i += M_PAR_THREADS) {
+            const int i2 = accepted[i];
+            if (i2 < 0) continue;
+            const int bin = rot_bin(k1[i].angle, k2[i2].angle);
+            binOf[i] = (uint8_t)bin;
+            atomicAdd(&S.hist[bin], 1);
+        }
+        __syncthreads();
+        int ind1, ind2, ind3;
+        three_maxima(S.hist, ind1, ind2, ind3);
+        __syncthreads();
+        if (t == 0) S.nmatches = 0;
+        __syncthreads();
+        int removed = 0;
+        for (int i = t; i < nq; i += M_PAR_THREADS) {
+            const int bin = binOf[i];
+            if (bin == 0xFF || bin == ind1 || bin == ind2 || bin == ind3) continue;
+            if (m12[i] >= 0) {  // :122-126 (a stolen match is already -1)
+                m12[i] = -1;
+                removed++;
+            }
+        }
+        if (removed) atomicAdd(&S.nmatches, removed);
+        __syncthreads();
+        nmatches -= S.nmatches;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int i = t; i < nq; i += M_PAR_THREADS) {  // :131-133
+        const int m = m12[i];
+        if (m >= 0) {
+            prev[2 * i] = k2[m].x;
+            prev[2 * i + 1] = k2[m].y;
+        }
+    }
+    if (t == 0) nmatchesOut[pair] = S.cut ? -1 : nmatches;
+#ifdef MATCH_PROFILE
+    if (pair == 0 && t == 0)
+        printf("pair 0: %d queries with candidates, %d rounds; set-up %.1f us, runs %.1f us, rest %.1f us\n", nActive, profRounds,
+               (double)(profT1 - profT0) / 100.0, (double)(profT2 - profT1) / 100.0, (double)(wall_clock64() - profT2) / 100.0);
+#endif
+}
+
 // ---- host side ------------------------------------------------------------------------
 struct MatchState {
     // Two pairs of error words (flags, pool entries asked for): [0..1] for the asynchronous entry point, read by
@@ -855,7 +1128,7 @@ static int match_window_batch(orb_ctx* c, int npairs, const orb_keypoint* d_k1, 
     hipStream_t st = (hipStream_t)stream;
     const GridGeom G = grid_geom(c, img_w, img_h);
     hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(256), 0, st, d_k2, d_n2, 0, stride2, G, B,
-                       errw);
+                       errw, 0);
     if ((rc = check_match_launch())) return rc;
     HIP_TRY(hipMemsetAsync(B.poolUsed, 0, 4, st));
     hipLaunchKernelGGL(k_match_lists<false>, dim3((stride1 + 3) / 4, npairs), dim3(256), 0, st, d_k1, d_d1, d_n1, 0,
@@ -863,10 +1136,15 @@ static int match_window_batch(orb_ctx* c, int npairs, const orb_keypoint* d_k1, 
                        (const float*)nullptr, (const int*)nullptr, (const int*)nullptr, d_d2, stride2, G, orb_ctx_quirks(c), B,
                        errw);
     if ((rc = check_match_launch())) return rc;
-    hipLaunchKernelGGL(k_match_resolve<0>, dim3(npairs), dim3(256), 0, st, d_k1, d_n1, 0, stride1, d_k2, d_n2, 0,
-                       stride2, d_prev_xy, d_matches12, (uint8_t*)s->binOf, (const float*)nullptr,
-                       (const uint8_t*)nullptr, (const uint8_t*)nullptr, (int*)nullptr, nnratio, 0, check_ori, B,
-                       d_nmatches, errw);
+    static const bool inOrder = getenv("ORBHIP_MATCH_IN_ORDER") != nullptr;  // the one-query-at-a-time walk (tests compare the two)
+    if (inOrder || stride1 > M_PAR_MAXKP || stride2 > M_PAR_MAXKP)  // (frames beyond what the 64-at-a-time kernel's LDS holds)
+        hipLaunchKernelGGL(k_match_resolve<0>, dim3(npairs), dim3(256), 0, st, d_k1, d_n1, 0, stride1, d_k2, d_n2, 0,
+                           stride2, d_prev_xy, d_matches12, (uint8_t*)s->binOf, (const float*)nullptr,
+                           (const uint8_t*)nullptr, (const uint8_t*)nullptr, (int*)nullptr, nnratio, 0, check_ori, B,
+                           d_nmatches, errw);
+    else
+        hipLaunchKernelGGL(k_match_resolve_window, dim3(npairs), dim3(M_PAR_THREADS), 0, st, d_k1, d_n1, stride1, d_k2, d_n2, stride2,
+                           d_prev_xy, d_matches12, (uint8_t*)s->binOf, nnratio, check_ori, B, d_nmatches, errw);
     return check_match_launch();
 }
 
@@ -1067,7 +1345,7 @@ static int match_projected_once(orb_ctx* c, int mode, const float* u, const floa
     HIP_TRY(hipMemcpyAsync(d, h, oM, hipMemcpyHostToDevice, st));
     const GridGeom G = grid_geom(c, img_w, img_h);
     hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, st, (const orb_keypoint*)(d + oK2), (const int*)nullptr, n2, n2,
-                       G, B, (int*)s->err + 2);
+                       G, B, (int*)s->err + 2, -1);
     if ((rc = check_match_launch())) return rc;
     HIP_TRY(hipMemsetAsync(B.poolUsed, 0, 4, st));
     hipLaunchKernelGGL(k_match_lists<true>, dim3((nq + 3) / 4, 1), dim3(256), 0, st, (const orb_keypoint*)nullptr,
@@ -1175,7 +1453,7 @@ extern "C" int orb_match_best(orb_ctx* c, const float* u, const float* v, const 
     HIP_TRY(hipMemcpyAsync(d, h, oIdx, hipMemcpyHostToDevice, st));
     const GridGeom G = grid_geom(c, img_w, img_h);
     hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, st, (const orb_keypoint*)(d + oK2), (const int*)nullptr, n2, n2,
-                       G, B, (int*)s->err + 2);
+                       G, B, (int*)s->err + 2, -1);
     if ((rc = check_match_launch())) return rc;
     hipLaunchKernelGGL(k_match_best, dim3((nq + 3) / 4), dim3(256), 0, st, (const float*)(d + oU), (const float*)(d + oV),
                        (const float*)(d + oR), (const int*)(d + oL0), (const int*)(d + oL1), (const uint8_t*)(d + oQ), nq,

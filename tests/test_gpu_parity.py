@@ -488,6 +488,55 @@ def test_matcher_wide_windows_use_the_candidate_pool(hip, oracle):
         c.close()
 
 
+def test_window_search_under_contention(hip, oracle):
+    """SearchForInitialization when many queries want the same keypoints (src/ORBmatcher.cc:63-64, 82-89): groups of
+    queries that are near-copies of ONE keypoint of the other frame at growing or shrinking distances (every
+    acceptance in a group hides the keypoint from the next query, or is stolen by it), exact ties, and chains in which
+    a query's second best is taken by the query before it.  The kernel resolves 64 queries at a time and has to stop
+    wherever an earlier query of the run disturbs a later one; the result must be the walk in order."""
+    w, h = 752, 480
+    rng = np.random.default_rng(11)
+    for case in range(6):
+        n2 = 1500
+        k2, d2 = _random_frame(hip, n2, w, h, 900 + case)
+        n1 = 1200
+        k1, d1 = _random_frame(hip, n1, w, h, 950 + case)
+        group = (2, 3, 8, 70, 5, 16)[case]          # queries per target keypoint (70: more than one run of 64)
+        order = rng.permutation(n1)
+        targets = rng.permutation(n2)
+        for g in range(n1 // group):
+            tgt = targets[g % n2]
+            members = order[g * group : (g + 1) * group] if case % 2 == 0 else np.sort(order[g * group : (g + 1) * group])
+            for r, q in enumerate(members):
+                d1[q] = d2[tgt]
+                # distance to the target: ascending, descending or equal along the group
+                nflip = (r % 12, (group - r) % 12, 3, r % 7, 2, (5 * r) % 11)[case]
+                bits = rng.choice(256, nflip, replace=False)
+                for b in bits:
+                    d1[q, b >> 3] ^= np.uint8(1 << (b & 7))
+                k1["x"][q] = np.clip(k2["x"][tgt] + rng.integers(-6, 7), 0, w - 1)
+                k1["y"][q] = np.clip(k2["y"][tgt] + rng.integers(-6, 7), 0, h - 1)
+                k1["angle"][q] = k2["angle"][tgt]
+        # a second keypoint next to every third target with a close descriptor: second bests that get taken
+        for g in range(0, min(n2, 300), 3):
+            a, b = targets[g], targets[(g + 1) % n2]
+            d2[b] = d2[a]
+            d2[b, 5] ^= np.uint8(0x0F)
+            k2["x"][b], k2["y"][b] = np.clip(k2["x"][a] + 2, 0, w - 1), k2["y"][a]
+        prev = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32)
+        c = _ctx(hip, "fork", 2000, 8, w, h)
+        most = 0
+        for (window, ratio, ori) in ((40, 0.9, True), (100, 0.99, False), (15, 0.7, True)):
+            ng, mg, pg = c.match_window(k1, d1, k2, d2, w, h, prev, window, ratio, ori)
+            no, mo, po = oracle.search_for_initialization(k1, d1, k2, d2, w, h, prev, window, ratio, ori, PRESETS["fork"])
+            assert ng == no, "case %d window %d" % (case, window)
+            np.testing.assert_array_equal(mg, mo, err_msg="case %d window %d" % (case, window))
+            np.testing.assert_array_equal(pg, po)
+            most = max(most, no)
+        assert most > 10, "case %d" % case
+        c.close()
+
+
 def test_out_of_range_angles_do_not_leave_the_histogram(hip, oracle):
     """The reference asserts that a rotation bin lies in [0, 30), which keypoint angles in [0, 360) guarantee.
     Angles a caller made up outside that range land in an extra bin no maximum can pick: those matches are
