@@ -96,7 +96,7 @@ static void run(int wavesPerSimd, int iters, float* dOut, unsigned long long* dC
     const double cyclesPerWave = (double)clk[0] / (double)clk[2];
     const double mhz = 100.0 * (double)clk[0] / (double)clk[1];
     // per SIMD: the wavefronts of a SIMD run side by side, so an iteration of all of them takes cyclesPerWave / iters
-    printf("%d MFMA + %3d VALU per iteration, %d wavefront(s) per SIMD: %7.1f cycles per iteration and wavefront, %7.1f per "
+    printf("%d accumulator sets (8 MFMA per iteration when > 0) + %3d VALU per iteration, %d wavefront(s) per SIMD: %7.1f cycles per iteration and wavefront, %7.1f per "
            "wavefront-iteration of the SIMD, %.3f ms, clock %4.0f MHz\n",
            NM, K, wavesPerSimd, cyclesPerWave / iters, cyclesPerWave / iters / wavesPerSimd, best, mhz);
     CHECK(hipEventDestroy(e0));

@@ -12,7 +12,7 @@
 //   - what does the exact loop of the scan kernel (rows broadcast from LDS,
 //     two queries per lane) sustain without any top-2 bookkeeping?
 // The engine clock during each run is reported from clock64() / wall_clock64().
-// Build: hipcc --offload-arch=gfx950 -O3 tools/valu_peak.hip -o tools/valu_peak
+// Build: python tools/gen_valu_banks.py && hipcc --offload-arch=gfx950 -O3 tools/valu_peak.hip -o tools/valu_peak
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
