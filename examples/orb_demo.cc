@@ -85,6 +85,16 @@ int main(int argc, char** argv) {
         if (vocPath && !voc.loadFromTextFile(vocPath)) return 8;
         Frame F1(imA, 0.0, &ext, vocPath ? &voc : nullptr, K, dist, 40.f, 35.f);
         std::vector<cv::Mat> pyrA = ext.GetImagePyramid();  // (downloaded on request; the member is not filled per frame)
+        // the levels with their 19-pixel rims (src/ORBextractor.cc:919-943), copied out before the next frame reuses the buffers
+        std::vector<std::vector<unsigned char> > padA;
+        for (cv::Mat& m : pyrA) {
+            std::vector<unsigned char> p;
+            for (int r = -19; r < m.rows + 19; r++) {
+                const unsigned char* row = m.data + (std::ptrdiff_t)r * (std::ptrdiff_t)m.step - 19;
+                p.insert(p.end(), row, row + m.cols + 38);
+            }
+            padA.push_back(p);
+        }
         for (cv::Mat& m : pyrA) m = m.clone();
         Frame F2(imB, 1.0, &ext, vocPath ? &voc : nullptr, K, dist, 40.f, 35.f);
 
@@ -195,6 +205,8 @@ int main(int argc, char** argv) {
             put(fo, &nLocal, 1);
             put(fo, local.data(), local.size());
         }
+        if (getenv("ORBDEMO_PADDING"))  // very last section: frame A's levels with their 19-pixel rims
+            for (const std::vector<unsigned char>& p : padA) put(fo, p.data(), p.size());
         fclose(fo);
         for (MapPoint* p : owned) delete p;
     } catch (const std::exception& e) {

@@ -109,17 +109,43 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     if (mbKeepPyramid) DownloadPyramid();
 }
 
+// src/ORBextractor.cc:913-949: every level is the centre of a buffer EDGE_THRESHOLD = 19 pixels larger on each side,
+// the rim filled by copyMakeBorder(BORDER_REFLECT_101) from the level's own pixels (level 0 likewise: the library sees
+// the caller's image through a pointer and a row stride, never what lies around it).  mvImagePyramid[level] is the
+// view of the centre, as there; the buffers belong to the extractor.
 void ORBextractor::DownloadPyramid() {
+    const int E = 19;
     std::vector<unsigned char*> dst(nlevels);
-    std::vector<int> step(nlevels);
+    std::vector<int> step(nlevels), ws(nlevels), hs(nlevels);
+    mvPaddedLevels.resize(nlevels);
     for (int l = 0; l < nlevels; l++) {
         int w = 0, h = 0;
         if (orb_get_pyramid_level(mpCtx, 0, l, nullptr, 0, &w, &h)) fail("orb_get_pyramid_level");
-        mvImagePyramid[l].create(h, w, CV_8UC1);
-        dst[l] = mvImagePyramid[l].data;
-        step[l] = (int)mvImagePyramid[l].step;
+        ws[l] = w;
+        hs[l] = h;
+        step[l] = w + 2 * E;
+        mvPaddedLevels[l].resize((size_t)step[l] * (h + 2 * E));
+        dst[l] = mvPaddedLevels[l].data() + (size_t)E * step[l] + E;
     }
     if (orb_get_pyramid(mpCtx, 0, dst.data(), step.data())) fail("orb_get_pyramid");  // one synchronisation for all levels
+    for (int l = 0; l < nlevels; l++) {
+        const int w = ws[l], h = hs[l], W = step[l];
+        unsigned char* c = dst[l];
+        if (w > E && h > E) {  // (reflection needs E pixels to mirror; every level the library accepts has them)
+            for (int y = 0; y < h; y++) {
+                unsigned char* r = c + (size_t)y * W;
+                for (int k = 1; k <= E; k++) {
+                    r[-k] = r[k];
+                    r[w - 1 + k] = r[w - 1 - k];
+                }
+            }
+            for (int k = 1; k <= E; k++) {
+                memcpy(c - (size_t)k * W - E, c + (size_t)k * W - E, (size_t)W);
+                memcpy(c + (size_t)(h - 1 + k) * W - E, c + (size_t)(h - 1 - k) * W - E, (size_t)W);
+            }
+        }
+        mvImagePyramid[l] = cv::Mat(h, w, CV_8UC1, c, (size_t)W);
+    }
     mbPyramidCurrent = true;
 }
 

@@ -35,12 +35,13 @@ public:
     std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
     std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
 
-    // Level images of the last frame (the ROI part of the reference's padded buffers,
-    // include/ORBextractor.h:71).  Nothing on the front-end path reads them, and copying eight
+    // Level images of the last frame (include/ORBextractor.h:71): as in the reference each is the centre
+    // view of a buffer 19 pixels larger on every side whose rim is the level reflected (BORDER_REFLECT_101,
+    // src/ORBextractor.cc:919-943).  Nothing on the front-end path reads them, and copying eight
     // levels back from the device costs more than the extraction of a 640x480 frame, so the member
     // is filled on request: GetImagePyramid() downloads the levels of the last frame (once per
     // frame); code that reads the member directly calls SetKeepPyramid(true) first, after which
-    // every operator() fills it as the reference does.
+    // every operator() fills it as the reference does.  The views point into buffers this object owns.
     std::vector<cv::Mat> mvImagePyramid;
 
     // ---- additions (no counterpart in the reference) -------------------------------
@@ -72,6 +73,7 @@ protected:
     unsigned mQuirks;
     int mDevice;
     std::vector<unsigned char> mKpBuf, mDescBuf;
+    std::vector<std::vector<unsigned char> > mvPaddedLevels;  // the buffers mvImagePyramid's views lie in
 };
 
 }  // namespace ORB_SLAM2

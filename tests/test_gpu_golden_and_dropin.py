@@ -73,7 +73,7 @@ def test_cpp_dropin_demo(oracle, tmp_path, preset):
         f.write(struct.pack("<iiiif", w, h, nf, window, ratio))
         f.write(a.tobytes())
         f.write(b.tobytes())
-    env = dict(os.environ, ORBHIP_QUIRKS=str(quirks), ORBDEMO_LOCALMAP="1")
+    env = dict(os.environ, ORBHIP_QUIRKS=str(quirks), ORBDEMO_LOCALMAP="1", ORBDEMO_PADDING="1")
     subprocess.check_call([exe, fin, fout], env=env, timeout=120)
     raw = open(fout, "rb").read()
     cnt = np.frombuffer(raw, np.int32, 8)
@@ -123,6 +123,12 @@ def test_cpp_dropin_demo(oracle, tmp_path, preset):
     take(KP, n1); take(KP, n2); take(np.float32, 4)  # undistorted keypoints (equal to the raw ones here), bounds
     n_local = int(take(np.int32, 1)[0])
     local = take(np.int32, n2)
+    # the buffers mvImagePyramid's views lie in: every level with a 19-pixel rim, reflected without repeating the edge
+    # pixel (copyMakeBorder(.., BORDER_REFLECT_101), src/ORBextractor.cc:919-943)
+    for l in range(nlev):
+        hl, wl = e.level(l).shape
+        padded = take(np.uint8, (wl + 38) * (hl + 38)).reshape(hl + 38, wl + 38)
+        assert (padded == np.pad(e.level(l), 19, mode="reflect")).all(), "padding of mvImagePyramid[%d]" % l
     assert off == len(raw)
     idx = np.nonzero(np.arange(n1) % 3 != 0)[0]
     r = np.where(idx % 2 != 0, _f32(2.5), _f32(4.0)).astype(np.float32) * _f32(3.0)
