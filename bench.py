@@ -431,6 +431,26 @@ def main():
             t = wall(sub, steps)
             sweep[str(nb)] = {"frames_per_s": round(nb / t, 1), "ms_per_batch": round(t * 1e3, 4)}
         sweep[str(B)] = {"frames_per_s": round(fps, 1), "ms_per_batch": round(dt / args.steps * 1e3, 4)}
+        # twice the headline batch (a context of its own, two of the batches above joined): what the launch boundaries cost
+        try:
+            ctxL = binding.Context(args.nfeatures, 1.2, 8, 20, 7, W, H, 2 * B, local, quirks)
+            d_two = [torch.cat([d_batches[i], d_batches[(i + 1) % 3]]) for i in range(3)]
+            d_kL = torch.zeros((2 * B, cap, 28), dtype=torch.uint8, device=dev)
+            d_dL = torch.zeros((2 * B, cap, 32), dtype=torch.uint8, device=dev)
+            d_cL = torch.zeros(2 * B, dtype=torch.int32, device=dev)
+            kL = [0]
+
+            def big():
+                ctxL.extract_batch_device(d_two[kL[0] % 3], d_kL, d_dL, d_cL, stream)
+                kL[0] += 1
+
+            t = wall(big, 10)
+            ctxL.check_last_batch()
+            sweep[str(2 * B)] = {"frames_per_s": round(2 * B / t, 1), "ms_per_batch": round(t * 1e3, 4)}
+            ctxL.close()
+            del d_two, d_kL, d_dL, d_cL
+        except Exception as ex:  # an extra, never a reason to lose the benchmark line
+            sweep[str(2 * B)] = {"error": str(ex)[-200:]}
         extras["batch_sweep"] = {"what": "device-resident frames, batches enqueued back to back, one synchronisation at the end",
                                  "by_batch": sweep}
         ctx.check_last_batch()

@@ -12,6 +12,7 @@
 //   environment ORBDEMO_VOC=<vocabulary text file> adds Frame::ComputeBoW on both frames, the L1 score of
 //   their bag-of-words vectors and ORBmatcher::SearchByBoW with frame A in the keyframe's place
 //   environment ORBDEMO_LOCALMAP=1 adds ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th)
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -76,8 +77,45 @@ int main(int argc, char** argv) {
             t0 = now_ms();
             for (int i = 0; i < reps; i++) Frame F(i & 1 ? imB : imA, (double)i, &ext, nullptr, K, dist, 40.f, 35.f);
             const double tFrame = (now_ms() - t0) / reps;
+            // the two searches of the tracking thread on a pair of frames (src/Tracking.cc:325-331, 638), as called there
+            Frame F1(imA, 0.0, &ext, nullptr, K, dist, 40.f, 35.f), F2(imB, 1.0, &ext, nullptr, K, dist, 40.f, 35.f);
+            ORBmatcher matcher(nnratio, true);
+            std::vector<cv::Point2f> prev0(F1.mvKeysUn.size()), prev;
+            for (size_t i = 0; i < prev0.size(); i++) prev0[i] = F1.mvKeysUn[i].pt;
+            std::vector<int> m12;
+            int nInit = 0;
+            for (int i = 0; i < 5; i++) { prev = prev0; nInit = matcher.SearchForInitialization(F1, F2, prev, m12, window); }
+            t0 = now_ms();
+            for (int i = 0; i < reps; i++) { prev = prev0; nInit = matcher.SearchForInitialization(F1, F2, prev, m12, window); }
+            const double tInit = (now_ms() - t0) / reps;
+            cv::Mat T(4, 4, CV_32F);
+            for (int i = 0; i < 16; i++) T.at<float>(i / 4, i % 4) = (i / 4 == i % 4) ? 1.f : 0.f;
+            F1.SetPose(T);
+            F2.SetPose(T);
+            std::vector<MapPoint*> owned;
+            for (int i = 0; i < F1.N; i++) {  // one map point per F1 keypoint, on its viewing ray at depth 2
+                const float z = 2.f;
+                const float x = (F1.mvKeysUn[i].pt.x - Frame::cx) * Frame::invfx * z;
+                const float y = (F1.mvKeysUn[i].pt.y - Frame::cy) * Frame::invfy * z;
+                owned.push_back(new MapPoint(x, y, z, F1.mDescriptors.ptr<unsigned char>(i), 1));
+                F1.mvpMapPoints[i] = owned.back();
+            }
+            int nProj = 0;
+            for (int i = 0; i < 5; i++) {
+                std::fill(F2.mvpMapPoints.begin(), F2.mvpMapPoints.end(), static_cast<MapPoint*>(NULL));
+                nProj = matcher.SearchByProjection(F2, F1, 15.f, true);
+            }
+            t0 = now_ms();
+            for (int i = 0; i < reps; i++) {
+                std::fill(F2.mvpMapPoints.begin(), F2.mvpMapPoints.end(), static_cast<MapPoint*>(NULL));  // src/Tracking.cc:636
+                nProj = matcher.SearchByProjection(F2, F1, 15.f, true);
+            }
+            const double tProj = (now_ms() - t0) / reps;
+            for (MapPoint* p : owned) delete p;
             printf("{\"cpp_operator_ms\": %.4f, \"cpp_operator_with_pyramid_download_ms\": %.4f, \"cpp_frame_constructor_ms\": %.4f, "
-                   "\"cpp_keypoints\": %d, \"cpp_repetitions\": %d}\n", tOp, tOpPyr, tFrame, (int)kps.size(), reps);
+                   "\"cpp_search_for_initialization_ms\": %.4f, \"cpp_search_by_projection_ms\": %.4f, \"cpp_init_matches\": %d, "
+                   "\"cpp_projection_matches\": %d, \"cpp_keypoints\": %d, \"cpp_repetitions\": %d}\n",
+                   tOp, tOpPyr, tFrame, tInit, tProj, nInit, nProj, (int)kps.size(), reps);
             return 0;
         }
         ORBVocabulary voc;

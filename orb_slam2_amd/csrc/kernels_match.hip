@@ -662,30 +662,34 @@ __global__ __launch_bounds__(256) void k_match_resolve(const orb_keypoint* __res
     if (t == 0) nmatchesOut[pair] = S.cut ? -1 : nmatches;
 }
 
-// Kernel 3 for the window search (SearchForInitialization), 64 queries at a time.
+// Kernel 3, 64 queries at a time.  MODE as in k_match_resolve: 0 window search (SearchForInitialization),
+// 1 projected search, best candidate only, 2 projected search with the local-map rule.
 //
-// Queries interact only through the keypoints they are matched to: an acceptance lowers vMatchedDistance of one
-// keypoint (src/ORBmatcher.cc:63-64, 89), which hides that keypoint from later queries whose distance to it is
-// not smaller.  The next 64 queries with candidates (a "run") are resolved together, four lanes per query, by
-// iteration: every query is evaluated against the state the runs before left AND the claims the earlier queries
-// of its own run made in the previous round (a claim = "query a accepts keypoint p at distance d"; what a later
-// query k sees of p is the claim of the last claimer before k, exactly what vMatchedDistance would hold when the
-// walk in order reaches k); queries whose outcome changed post their new claim, and the rounds go on until
-// nothing changes.  Query 0 of the run sees no claims and is final after round 1, query 1 after round 2 at the
-// latest, and so on: the iteration ends, in at most 65 rounds, at the outcome of the walk in order (its only fixed
-// point).  On ordinary frames three to five rounds do.  Then the run is committed: state per keypoint, by sorted
-// position, is distance << 16 | owner, so that an atomic minimum keeps the latest (smallest) accepted distance.
-// The lists of the next run are fetched while the rounds of the current one go on.  Everything after the walk
-// (vnMatches12 from the final owners, rotation histogram over all acceptances, three maxima, removal,
-// vbPrevMatched) is as in k_match_resolve<0>.
+// Queries interact only through the keypoints they are matched to.  Window search: an acceptance lowers
+// vMatchedDistance of one keypoint (src/ORBmatcher.cc:63-64, 89), which hides that keypoint from later queries whose
+// distance to it is not smaller.  Projected searches: an acceptance by a map point with observations occupies the
+// keypoint (:345-347) and hides it from every later query.  The next 64 queries with candidates (a "run") are
+// resolved together, 16 lanes per query, by iteration: every query is evaluated against the state the runs before
+// left AND the claims the earlier queries of its own run made in the previous round (a claim = "query a accepts
+// keypoint p"; what a later query k sees of p is the claim of the last claimer before k, exactly what the state
+// would hold when the walk in order reaches k); queries whose outcome changed post their new claim, and the rounds
+// go on until nothing changes.  Query 0 of the run sees no claims and is final after round 1, query 1 after round 2
+// at the latest, and so on: the iteration ends, in at most 65 rounds, at the outcome of the walk in order (its only
+// fixed point).  On ordinary frames two or three rounds do.  Then the run is committed.  State per keypoint, by
+// sorted position -- window search: distance << 16 | owner, so that an atomic minimum keeps the latest (smallest)
+// accepted distance; projected: the owner (the last query that took the keypoint: an atomic maximum) and an
+// occupancy flag next to the keypoint's octave.  The lists of the next run are fetched while the rounds of the
+// current one go on.  Everything after the walk (vnMatches12 / the map-point assignment from the final owners,
+// rotation histogram over all acceptances, three maxima, removal, vbPrevMatched) is as in k_match_resolve.
 #define M_RUN 64            // queries resolved together
 #define M_PAR_MAXKP 4096    // keypoints of the searched frame, and queries with candidates, this kernel's LDS holds
 #define M_TILE_W 128        // list entries per query held in LDS (the rest is read from the list itself)
 #define M_TILE_PITCH 129
 #define M_PAR_THREADS 1024  // sixteen lanes per query of a run
 struct ResolveParLds {
-    unsigned long long claims[M_PAR_MAXKP];  // by sorted position: bit k = query k of the run claims the keypoint
-    uint32_t so[M_PAR_MAXKP];                // vMatchedDistance << 16 | vnMatches21 (0xFFFFFFFF: INT_MAX, -1)
+    unsigned long long claims[M_PAR_MAXKP];  // by sorted position: bit k = query k of the run claims the keypoint (projected: and occupies it)
+    uint32_t so[M_PAR_MAXKP];                // window: vMatchedDistance << 16 | vnMatches21 (0xFFFFFFFF: INT_MAX, -1); projected: owner + 1 (0: none)
+    uint16_t occ[M_PAR_MAXKP];               // projected: occupancy flag (bit 0), octave << 8
     uint16_t idx[M_PAR_MAXKP];               // keypoint index by sorted position
     uint16_t qI1[M_PAR_MAXKP], qCnt[M_PAR_MAXKP];  // the queries with candidates, in order: index, list length
     uint32_t tile[2][M_RUN * M_TILE_PITCH];  // first entries of the run's lists, double buffered
@@ -696,30 +700,33 @@ struct ResolveParLds {
     int nmatches, cut;
 };
 
-__global__ __launch_bounds__(M_PAR_THREADS) void k_match_resolve_window(const orb_keypoint* __restrict__ k1all,
-                                                              const int* __restrict__ n1s, int stride1,
+template <int MODE>
+__global__ __launch_bounds__(M_PAR_THREADS) void k_match_resolve_par(const orb_keypoint* __restrict__ k1all,
+                                                              const int* __restrict__ n1s, int nqConst, int stride1,
                                                               const orb_keypoint* __restrict__ k2all,
-                                                              const int* __restrict__ n2s, int stride2,
+                                                              const int* __restrict__ n2s, int n2const, int stride2,
                                                               float* __restrict__ prevAll, int* __restrict__ m12All,
-                                                              uint8_t* __restrict__ binOfAll, float nnratio, int checkOri,
+                                                              uint8_t* __restrict__ binOfAll, const float* __restrict__ qangle,
+                                                              const uint8_t* __restrict__ qobs,
+                                                              const uint8_t* __restrict__ occupied2, int* __restrict__ match2,
+                                                              float nnratio, int thHigh, int checkOri,
                                                               MatchBuffers B, int* __restrict__ nmatchesOut,
                                                               int* __restrict__ error) {
     __shared__ ResolveParLds S;
-#ifdef MATCH_PROFILE
-    const unsigned long long profT0 = wall_clock64();
-#endif
+    constexpr bool PROJECTED = MODE != 0;
     const int pair = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const orb_keypoint* k1 = k1all + (int64_t)pair * stride1;
+    const orb_keypoint* k1 = PROJECTED ? nullptr : k1all + (int64_t)pair * stride1;
     const orb_keypoint* k2 = k2all + (int64_t)pair * stride2;
-    float* prev = prevAll + (int64_t)pair * stride1 * 2;
-    int* m12 = m12All + (int64_t)pair * stride1;
+    float* prev = PROJECTED ? nullptr : prevAll + (int64_t)pair * stride1 * 2;
+    int* m12 = PROJECTED ? nullptr : m12All + (int64_t)pair * stride1;
     uint8_t* binOf = binOfAll + (int64_t)pair * stride1;
     const int* counts = B.counts + (int64_t)pair * stride1;
     int* accepted = B.accepted + (int64_t)pair * stride1;
     const uint32_t* lists = B.lists + (int64_t)pair * stride1 * B.capQ;
     const int* cellStart = B.cellStart + (int64_t)pair * (M_CELLS + 1);
     const uint32_t* gS = B.gSorted + (int64_t)pair * stride2;
-    const int nq = n1s[pair], n2 = n2s[pair];
+    const int nq = PROJECTED ? nqConst : n1s[pair];
+    const int n2 = n2s ? n2s[pair] : n2const;
     if (nq > stride1 || nq > M_PAR_MAXKP || n2 > stride2 || n2 > M_PAR_MAXKP) {  // (the host picks this kernel by the strides)
         if (t == 0) {
             atomicOr(error, M_ERR_LIMIT);
@@ -729,14 +736,22 @@ __global__ __launch_bounds__(M_PAR_THREADS) void k_match_resolve_window(const or
     }
     const int nIn = cellStart[M_CELLS];
     for (int i = t; i < nq; i += M_PAR_THREADS) {
-        m12[i] = -1;
+        if (!PROJECTED) m12[i] = -1;
         binOf[i] = 0xFF;
         accepted[i] = -1;
     }
+    if (PROJECTED)
+        for (int i = t; i < n2; i += M_PAR_THREADS) match2[i] = -1;
     for (int p = t; p < nIn; p += M_PAR_THREADS) {
-        S.idx[p] = (uint16_t)(gS[p] & 0xFFFFu);
-        S.so[p] = 0xFFFFFFFFu;
+        const int i2 = (int)(gS[p] & 0xFFFFu);
+        S.idx[p] = (uint16_t)i2;
         S.claims[p] = 0ull;
+        if (PROJECTED) {
+            S.so[p] = 0u;
+            S.occ[p] = (uint16_t)((MODE == 2 ? (uint32_t)B.gOct[(int64_t)pair * stride2 + p] << 8 : 0u) | (occupied2 && occupied2[i2] ? 1u : 0u));
+        } else {
+            S.so[p] = 0xFFFFFFFFu;
+        }
     }
     if (t <= ORB_HISTO) S.hist[t] = 0;
     if (t == 0) {
@@ -797,10 +812,6 @@ __global__ __launch_bounds__(M_PAR_THREADS) void k_match_resolve_window(const or
     }
     __syncthreads();
 
-#ifdef MATCH_PROFILE
-    int profRounds = 0;
-    const unsigned long long profT1 = wall_clock64();
-#endif
     int flip = 0;  // which of the two `changed` words the current round uses
     for (int base = 0, buf = 0; base < nActive; base += M_RUN, buf ^= 1) {
         const int a = base + kq;
@@ -808,6 +819,7 @@ __global__ __launch_bounds__(M_PAR_THREADS) void k_match_resolve_window(const or
         const int i1 = in ? (int)S.qI1[a] : 0;
         int cnt = in ? (int)S.qCnt[a] : 0;
         if (cnt == 0xFFFF) cnt = counts[i1];
+        const int obs = (PROJECTED && qobs && in) ? (int)qobs[i1] : 1;  // projected: the map point has observations
         if (base + M_RUN < nActive) fetch(base + M_RUN);  // in flight during the rounds below
         const uint32_t* row = &S.tile[buf][kq * M_TILE_PITCH];
         const uint32_t* seg = lists + (int64_t)i1 * B.capQ;
@@ -816,14 +828,19 @@ __global__ __launch_bounds__(M_PAR_THREADS) void k_match_resolve_window(const or
         if (sub == 15) S.k1[kq] = 0xFFFFFFFFu;
         uint32_t mine = 0xFFFFFFFFu;  // this query's claim as posted (best key when accepted)
         __syncthreads();
-        for (int round = 0;; round++) {
+        for (;;) {
             // evaluate against the committed state and the earlier queries' claims of the previous round
             uint32_t a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu;
             auto consider = [&](uint32_t e) {
                 const uint32_t p = e & 0xFFFFu, d = e >> 16;
-                bool hidden = (S.so[p] >> 16) <= d;  // :63-64
                 const unsigned long long m = S.claims[p] & earlier;
-                if (m) hidden = hidden || (S.k1[63 - __clzll(m)] >> 16) <= d;  // the last claimer before this query
+                bool hidden;
+                if (PROJECTED) {
+                    hidden = (S.occ[p] & 1u) != 0 || m != 0ull;  // :345-347 (claims are only posted by map points with observations)
+                } else {
+                    hidden = (S.so[p] >> 16) <= d;  // :63-64
+                    if (m) hidden = hidden || (S.k1[63 - __clzll(m)] >> 16) <= d;  // the last claimer before this query
+                }
                 if (!hidden) {
                     a2 = min(a2, max(a1, e));
                     a1 = min(a1, e);
@@ -839,13 +856,29 @@ __global__ __launch_bounds__(M_PAR_THREADS) void k_match_resolve_window(const or
             uint32_t now = 0xFFFFFFFFu;
             if (a1 != 0xFFFFFFFFu) {
                 const int bestDist = (int)(a1 >> 16);
-                const float bestDist2 = (a2 == 0xFFFFFFFFu) ? (float)INT_MAX : (float)(int)(a2 >> 16);
-                if (bestDist <= M_TH_LOW && (float)bestDist < __fmul_rn(bestDist2, nnratio)) now = a1;  // :78-80
+                bool accept;
+                if (MODE == 1) {
+                    accept = bestDist < 256 && bestDist <= thHigh;  // bestDist starts at 256 with strict '<', :339,357,363
+                } else if (MODE == 2) {
+                    // both distances start at 256 and both levels at -1; a candidate at distance 256 replaces neither
+                    accept = bestDist < 256 && bestDist <= thHigh;
+                    const int dist2 = (a2 == 0xFFFFFFFFu) ? 256 : (int)(a2 >> 16);
+                    if (accept && dist2 < 256) {
+                        const uint32_t lv1 = S.occ[a1 & 0xFFFFu] >> 8, lv2 = S.occ[a2 & 0xFFFFu] >> 8;
+                        if (lv1 == lv2 && (float)bestDist > __fmul_rn(nnratio, (float)dist2)) accept = false;
+                    }
+                } else {
+                    const float bestDist2 = (a2 == 0xFFFFFFFFu) ? (float)INT_MAX : (float)(int)(a2 >> 16);
+                    accept = bestDist <= M_TH_LOW && (float)bestDist < __fmul_rn(bestDist2, nnratio);  // :78-80
+                }
+                if (accept) now = a1;
             }
             __syncthreads();  // every query has read the claims of the previous round
             if (sub == 15 && in && now != mine) {
-                if (mine != 0xFFFFFFFFu) atomicAnd(&S.claims[mine & 0xFFFFu], ~(1ull << kq));
-                if (now != 0xFFFFFFFFu) atomicOr(&S.claims[now & 0xFFFFu], 1ull << kq);
+                // (projected: a map point without observations takes the keypoint but does not occupy it: no claim)
+                const bool claims = !PROJECTED || obs != 0;
+                if (claims && mine != 0xFFFFFFFFu) atomicAnd(&S.claims[mine & 0xFFFFu], ~(1ull << kq));
+                if (claims && now != 0xFFFFFFFFu) atomicOr(&S.claims[now & 0xFFFFu], 1ull << kq);
                 S.k1[kq] = now;
                 S.changed[flip] = 1;
             }
@@ -854,46 +887,49 @@ __global__ __launch_bounds__(M_PAR_THREADS) void k_match_resolve_window(const or
             __syncthreads();
             const int again = S.changed[flip];
             flip ^= 1;
-#ifdef MATCH_PROFILE
-            profRounds++;
-#endif
             if (!again) break;
         }
         // commit the run; take its claims back
         if (sub == 15 && in && mine != 0xFFFFFFFFu) {
             const uint32_t pos = mine & 0xFFFFu;
-            atomicMin(&S.so[pos], ((mine >> 16) << 16) | (uint32_t)i1);
+            if (PROJECTED) {
+                atomicMax(&S.so[pos], (uint32_t)i1 + 1u);  // the keypoint holds the map point of its last taker
+                if (obs) S.occ[pos] |= 1u;                  // (several takers of one keypoint: at most the last has observations; all write 1)
+                atomicAdd(&S.nmatches, 1);                  // every acceptance counts (:364-366)
+            } else {
+                atomicMin(&S.so[pos], ((mine >> 16) << 16) | (uint32_t)i1);
+            }
             accepted[i1] = (int)S.idx[pos];
             S.claims[pos] = 0ull;
         }
         if (base + M_RUN < nActive) stash(buf ^ 1);
         __syncthreads();
     }
-#ifdef MATCH_PROFILE
-    const unsigned long long profT2 = wall_clock64();
-#endif
-    // vnMatches12: query i1 holds keypoint i2 exactly when i2's owner is i1 at the end, a stolen match having
-    // lost its owner (:82-86)
+    // Window search: query i1 holds keypoint i2 exactly when i2's owner is i1 at the end, a stolen match having lost
+    // its owner (:82-86).  Projected search: the keypoint holds the map point of its last taker.
     __threadfence_block();
     __syncthreads();
     {
         int mine = 0;
         for (int p = t; p < nIn; p += M_PAR_THREADS) {
             const uint32_t v = S.so[p];
-            if (v == 0xFFFFFFFFu) continue;
-            m12[v & 0xFFFFu] = S.idx[p];
-            mine++;
+            if (PROJECTED) {
+                if (v != 0u) match2[S.idx[p]] = (int)v - 1;
+            } else if (v != 0xFFFFFFFFu) {
+                m12[v & 0xFFFFu] = S.idx[p];
+                mine++;
+            }
         }
-        if (mine) atomicAdd(&S.nmatches, mine);
+        if (!PROJECTED && mine) atomicAdd(&S.nmatches, mine);
     }
     __threadfence_block();
     __syncthreads();
     int nmatches = S.nmatches;
-    if (checkOri) {  // :88-99 after the fact: one histogram entry per acceptance
+    if (checkOri) {  // :88-99 / :371-383 after the fact: one histogram entry per acceptance
         for (int i = t; i < nq; i += M_PAR_THREADS) {
             const int i2 = accepted[i];
             if (i2 < 0) continue;
-            const int bin = rot_bin(k1[i].angle, k2[i2].angle);
+            const int bin = rot_bin(PROJECTED ? qangle[i] : k1[i].angle, k2[i2].angle);
             binOf[i] = (uint8_t)bin;
             atomicAdd(&S.hist[bin], 1);
         }
@@ -907,7 +943,10 @@ __global__ __launch_bounds__(M_PAR_THREADS) void k_match_resolve_window(const or
         for (int i = t; i < nq; i += M_PAR_THREADS) {
             const int bin = binOf[i];
             if (bin == 0xFF || bin == ind1 || bin == ind2 || bin == ind3) continue;
-            if (m12[i] >= 0) {  // :122-126 (a stolen match is already -1)
+            if (PROJECTED) {
+                match2[accepted[i]] = -2;  // :400-401, once per list entry (-2: assigned, then cleared)
+                removed++;
+            } else if (m12[i] >= 0) {  // :122-126 (a stolen match is already -1)
                 m12[i] = -1;
                 removed++;
             }
@@ -916,21 +955,18 @@ __global__ __launch_bounds__(M_PAR_THREADS) void k_match_resolve_window(const or
         __syncthreads();
         nmatches -= S.nmatches;
     }
-    __threadfence_block();
-    __syncthreads();
-    for (int i = t; i < nq; i += M_PAR_THREADS) {  // :131-133
-        const int m = m12[i];
-        if (m >= 0) {
-            prev[2 * i] = k2[m].x;
-            prev[2 * i + 1] = k2[m].y;
+    if (!PROJECTED) {
+        __threadfence_block();
+        __syncthreads();
+        for (int i = t; i < nq; i += M_PAR_THREADS) {  // :131-133
+            const int m = m12[i];
+            if (m >= 0) {
+                prev[2 * i] = k2[m].x;
+                prev[2 * i + 1] = k2[m].y;
+            }
         }
     }
     if (t == 0) nmatchesOut[pair] = S.cut ? -1 : nmatches;
-#ifdef MATCH_PROFILE
-    if (pair == 0 && t == 0)
-        printf("pair 0: %d queries with candidates, %d rounds; set-up %.1f us, runs %.1f us, rest %.1f us\n", nActive, profRounds,
-               (double)(profT1 - profT0) / 100.0, (double)(profT2 - profT1) / 100.0, (double)(wall_clock64() - profT2) / 100.0);
-#endif
 }
 
 // ---- host side ------------------------------------------------------------------------
@@ -1143,8 +1179,10 @@ static int match_window_batch(orb_ctx* c, int npairs, const orb_keypoint* d_k1, 
                            (const uint8_t*)nullptr, (const uint8_t*)nullptr, (int*)nullptr, nnratio, 0, check_ori, B,
                            d_nmatches, errw);
     else
-        hipLaunchKernelGGL(k_match_resolve_window, dim3(npairs), dim3(M_PAR_THREADS), 0, st, d_k1, d_n1, stride1, d_k2, d_n2, stride2,
-                           d_prev_xy, d_matches12, (uint8_t*)s->binOf, nnratio, check_ori, B, d_nmatches, errw);
+        hipLaunchKernelGGL(k_match_resolve_par<0>, dim3(npairs), dim3(M_PAR_THREADS), 0, st, d_k1, d_n1, 0, stride1, d_k2, d_n2, 0,
+                           stride2, d_prev_xy, d_matches12, (uint8_t*)s->binOf, (const float*)nullptr,
+                           (const uint8_t*)nullptr, (const uint8_t*)nullptr, (int*)nullptr, nnratio, 0, check_ori, B,
+                           d_nmatches, errw);
     return check_match_launch();
 }
 
@@ -1353,7 +1391,10 @@ static int match_projected_once(orb_ctx* c, int mode, const float* u, const floa
                        (const float*)(d + oU), (const float*)(d + oV), (const float*)(d + oR), (const int*)(d + oL0),
                        (const int*)(d + oL1), (const uint8_t*)(d + oD2), n2, G, orb_ctx_quirks(c), B, (int*)s->err + 2);
     if ((rc = check_match_launch())) return rc;
-    hipLaunchKernelGGL(mode == 2 ? k_match_resolve<2> : k_match_resolve<1>, dim3(1), dim3(256), 0, st,
+    static const bool inOrder = getenv("ORBHIP_MATCH_IN_ORDER") != nullptr;
+    const bool par = !inOrder && nq <= M_PAR_MAXKP && n2 <= M_PAR_MAXKP;
+    hipLaunchKernelGGL(par ? (mode == 2 ? k_match_resolve_par<2> : k_match_resolve_par<1>) : (mode == 2 ? k_match_resolve<2> : k_match_resolve<1>),
+                       dim3(1), dim3(par ? M_PAR_THREADS : 256), 0, st,
                        (const orb_keypoint*)nullptr, (const int*)nullptr, nq, nq, (const orb_keypoint*)(d + oK2),
                        (const int*)nullptr, n2, n2, (float*)nullptr, (int*)nullptr, (uint8_t*)s->binOf,
                        (const float*)(d + oA), qobs ? (const uint8_t*)(d + oObs) : (const uint8_t*)nullptr,

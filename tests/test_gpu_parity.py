@@ -584,6 +584,58 @@ def test_search_by_projection(hip, oracle, preset):
     c.close()
 
 
+def test_projected_searches_under_contention(hip, oracle):
+    """SearchByProjection(Frame&, const Frame&, ..) and the local-map search when groups of queries want the same
+    keypoint (src/ORBmatcher.cc:345-347, 364-366): the first map point WITH observations that takes a keypoint
+    occupies it for every later query, map points without observations take it without occupying it, and the last
+    taker's map point stays.  The kernel resolves 64 queries at a time; the result must be the walk in order."""
+    w, h = 640, 480
+    rng = np.random.default_rng(5)
+    scale = oracle.Extractor(1000, 1.2, 8, 20, 7, PRESETS["fork"]).tables()["scale"]
+    for case in range(4):
+        n2, nq = 1200, 1100
+        k2, d2 = _random_frame(hip, n2, w, h, 700 + case)
+        k2["octave"] = rng.integers(0, 3, n2)
+        kq, dq = _random_frame(hip, nq, w, h, 750 + case)
+        group = (3, 9, 70, 5)[case]
+        targets = rng.permutation(n2)
+        u = kq["x"].copy()
+        v = kq["y"].copy()
+        lvl = rng.integers(0, 3, nq).astype(np.int32)
+        for g in range(nq // group):
+            tgt = targets[g % n2]
+            for r in range(group):
+                q = g * group + r
+                dq[q] = d2[tgt]
+                for b in rng.choice(256, int(rng.integers(0, 9)), replace=False):
+                    dq[q, b >> 3] ^= np.uint8(1 << (b & 7))
+                u[q] = np.clip(k2["x"][tgt] + rng.integers(-3, 4), 0, w - 1)
+                v[q] = np.clip(k2["y"][tgt] + rng.integers(-3, 4), 0, h - 1)
+                lvl[q] = k2["octave"][tgt]
+                kq["angle"][q] = k2["angle"][tgt]
+            # a near-twin of the target next to it: the group's second choice
+            tw = targets[(g + n2 // 2) % n2]
+            d2[tw] = d2[tgt]
+            d2[tw, 7] ^= np.uint8(0x33)
+            k2["x"][tw], k2["y"][tw], k2["octave"][tw] = np.clip(k2["x"][tgt] + 1, 0, w - 1), k2["y"][tgt], k2["octave"][tgt]
+        qobs = (rng.integers(0, 3, nq) != 0).astype(np.uint8)  # a third of the map points have no observations
+        occ = (rng.integers(0, 13, n2) == 0).astype(np.uint8)
+        radius = (np.float32(15) * scale[lvl]).astype(np.float32)
+        c = _ctx(hip, "fork", 1000, 8, w, h)
+        for ori in (True, False):
+            ng, mg = c.match_projected(u, v, radius, lvl - 1, lvl + 1, kq["angle"], dq, qobs, k2, d2, w, h, occ, 100, ori)
+            no, mo = oracle.search_by_projection(u, v, radius, lvl - 1, lvl + 1, kq["angle"], dq, qobs, k2, d2, w, h, occ, 100, ori, PRESETS["fork"])
+            assert ng == no, "case %d ori %s" % (case, ori)
+            np.testing.assert_array_equal(mg, mo, err_msg="case %d ori %s" % (case, ori))
+        assert no > 20
+        for ratio in (0.8, 0.99):
+            ng, mg = c.match_local_map(u, v, radius, lvl - 1, lvl, dq, qobs, k2, d2, w, h, occ, 100, ratio)
+            no, mo = oracle.search_local_map(u, v, radius, lvl - 1, lvl, dq, qobs, k2, d2, w, h, occ, 100, ratio, PRESETS["fork"])
+            assert ng == no, "local map, case %d ratio %s" % (case, ratio)
+            np.testing.assert_array_equal(mg, mo)
+        c.close()
+
+
 def test_hamming_host(hip, oracle):
     d = synth_descriptors(200, 5)
     for i in range(199):
