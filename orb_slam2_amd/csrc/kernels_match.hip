@@ -971,9 +971,9 @@ __global__ __launch_bounds__(M_PAR_THREADS) void k_match_resolve_par(const orb_k
 
 // ---- host side ------------------------------------------------------------------------
 struct MatchState {
-    // Two pairs of error words (flags, pool entries asked for): [0..1] for the asynchronous entry point, read by
-    // orb_check_last_batch; [2..3] for the host-pointer entry points, which read and clear theirs before they
-    // return.  A pending asynchronous report thus survives any synchronous call made before it is collected.
+    // Error words (flags, pool entries asked for) of the asynchronous entry point, read by orb_check_last_batch.
+    // A host-pointer entry point keeps its own pair inside the block it uploads and downloads, so a pending
+    // asynchronous report survives any synchronous call made before it is collected.
     void* err = nullptr;
     // scratch, grown on demand and kept
     void* gSorted = nullptr; void* gXY = nullptr; void* gOct = nullptr; void* cellStart = nullptr;
@@ -1008,6 +1008,7 @@ int orb_ctx_device(const orb_ctx* c);
 unsigned orb_ctx_quirks(const orb_ctx* c);
 int orb_ctx_max_batch(const orb_ctx* c);
 void** orb_ctx_match_state(orb_ctx* c);
+void* orb_ctx_stream(orb_ctx* c);  // the context's own (non-blocking) stream: the host-pointer entry points run on it
 
 static int grow(void** p, size_t bytes) {
     if (*p) {
@@ -1028,12 +1029,12 @@ static int grow(void** p, size_t bytes) {
 
 // Makes the scratch large enough for npairs pairs of (stride1 queries, stride2 searched keypoints).
 static int match_buffers(orb_ctx* c, int npairs, int stride1, int stride2, MatchState** out, MatchBuffers* B,
-                         bool sync = true, int** errw = nullptr) {
+                         int** errw = nullptr) {
     void** slot = orb_ctx_match_state(c);
     if (!*slot) {
         MatchState* s = new MatchState();
-        hipError_t e = hipMalloc(&s->err, 16);
-        if (e == hipSuccess) e = hipMemset(s->err, 0, 16);
+        hipError_t e = hipMalloc(&s->err, 8);
+        if (e == hipSuccess) e = hipMemset(s->err, 0, 8);
         if (e != hipSuccess) {
             delete s;
             orb_set_error("matcher state allocation failed: %s", hipGetErrorString(e));
@@ -1098,9 +1099,9 @@ static int match_buffers(orb_ctx* c, int npairs, int stride1, int stride2, Match
     B->pool = (uint32_t*)s->pool;
     B->ovfStart = (int*)s->ovfStart;
     B->poolCap = (unsigned)s->poolCap;
-    int* const words = (int*)s->err + (sync ? 2 : 0);
-    B->poolUsed = (unsigned*)words + 1;
-    if (errw) *errw = words;
+    // the asynchronous entry points' error words; a host-pointer entry point points these at its own block instead
+    B->poolUsed = (unsigned*)s->err + 1;
+    if (errw) *errw = (int*)s->err;
     *out = s;
     return ORB_OK;
 }
@@ -1140,7 +1141,7 @@ static int match_window_batch(orb_ctx* c, int npairs, const orb_keypoint* d_k1, 
                               const int* d_n1, int stride1, const orb_keypoint* d_k2,
                               const uint8_t* d_d2, const int* d_n2, int stride2, int img_w, int img_h,
                               float* d_prev_xy, int* d_matches12, int window, float nnratio,
-                              int check_ori, int* d_nmatches, void* stream, bool sync) {
+                              int check_ori, int* d_nmatches, void* stream, bool sync, int* blockErr = nullptr) {
     if (!c || npairs < 1 || !d_k1 || !d_d1 || !d_n1 || !d_k2 || !d_d2 || !d_n2 || !d_prev_xy || !d_matches12 ||
         !d_nmatches || stride1 < 1 || stride2 < 1 || img_w < 1 || img_h < 1) {
         orb_set_error("orb_match_window_batch_device: bad arguments");
@@ -1159,14 +1160,18 @@ static int match_window_batch(orb_ctx* c, int npairs, const orb_keypoint* d_k1, 
     MatchState* s = nullptr;
     MatchBuffers B;
     int* errw = nullptr;
-    int rc = match_buffers(c, npairs, stride1, stride2, &s, &B, sync, &errw);
+    int rc = match_buffers(c, npairs, stride1, stride2, &s, &B, &errw);
     if (rc) return rc;
+    if (blockErr) {  // error words inside the caller's block (both zero on arrival)
+        errw = blockErr;
+        B.poolUsed = (unsigned*)blockErr + 1;
+    }
     hipStream_t st = (hipStream_t)stream;
     const GridGeom G = grid_geom(c, img_w, img_h);
     hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(256), 0, st, d_k2, d_n2, 0, stride2, G, B,
                        errw, 0);
     if ((rc = check_match_launch())) return rc;
-    HIP_TRY(hipMemsetAsync(B.poolUsed, 0, 4, st));
+    if (!blockErr) HIP_TRY(hipMemsetAsync(B.poolUsed, 0, 4, st));
     hipLaunchKernelGGL(k_match_lists<false>, dim3((stride1 + 3) / 4, npairs), dim3(256), 0, st, d_k1, d_d1, d_n1, 0,
                        stride1, (const float*)d_prev_xy, (float)window, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const int*)nullptr, (const int*)nullptr, d_d2, stride2, G, orb_ctx_quirks(c), B,
@@ -1232,7 +1237,9 @@ static int ensure_block(MatchState* s, size_t bytes) {
 #define M_RETRY 1
 static int match_error(const int* flag, MatchState* s, const char* what, bool mayRetry, bool sync = true) {
     if (flag[0]) {
-        HIP_TRY(hipMemset((int*)s->err + (sync ? 2 : 0), 0, 4));
+        // (the host-pointer entry points keep their two error words inside the call's block, uploaded as zeros with
+        // the inputs and fetched with the outputs: nothing of theirs stays on the device)
+        if (!sync) HIP_TRY(hipMemset(s->err, 0, 4));
         if (flag[0] & M_ERR_LIMIT) {
             orb_set_error("%s: keypoint count exceeds the kernel's limits", what);
             return ORB_ERR_CAPACITY;
@@ -1291,7 +1298,8 @@ static int match_window_once(orb_ctx* c, const orb_keypoint* k1, const uint8_t* 
     const size_t oK1 = L.add((size_t)n1 * sizeof(orb_keypoint)), oD1 = L.add((size_t)n1 * 32);
     const size_t oK2 = L.add((size_t)s2 * sizeof(orb_keypoint)), oD2 = L.add((size_t)s2 * 32), oN = L.add(8);
     const size_t oPrev = L.add((size_t)n1 * 8);  // in and out
-    const size_t oM = L.add((size_t)n1 * 4), oNm = L.add(4), oErr = L.add(8);
+    const size_t oErr = L.add(8);                // error words: zero in, fetched with the outputs
+    const size_t oM = L.add((size_t)n1 * 4), oNm = L.add(4);
     if ((rc = ensure_block(s, L.off))) return rc;
     uint8_t* h = (uint8_t*)s->blockHost;
     uint8_t* d = (uint8_t*)s->blockDev;
@@ -1304,14 +1312,16 @@ static int match_window_once(orb_ctx* c, const orb_keypoint* k1, const uint8_t* 
     const int ns[2] = {n1, n2};
     memcpy(h + oN, ns, 8);
     memcpy(h + oPrev, prev_xy, (size_t)n1 * 8);
-    HIP_TRY(hipMemcpyAsync(d, h, oM, hipMemcpyHostToDevice, nullptr));
+    memset(h + oErr, 0, 8);
+    hipStream_t st = (hipStream_t)orb_ctx_stream(c);
+    HIP_TRY(hipMemcpyAsync(d, h, oM, hipMemcpyHostToDevice, st));
     rc = match_window_batch(c, 1, (const orb_keypoint*)(d + oK1), d + oD1, (const int*)(d + oN), s1,
                             (const orb_keypoint*)(d + oK2), d + oD2, (const int*)(d + oN) + 1, s2, img_w, img_h,
-                            (float*)(d + oPrev), (int*)(d + oM), window, nnratio, check_ori, (int*)(d + oNm), nullptr, true);
+                            (float*)(d + oPrev), (int*)(d + oM), window, nnratio, check_ori, (int*)(d + oNm), st, true,
+                            (int*)(d + oErr));
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(d + oErr, (int*)s->err + 2, 8, hipMemcpyDeviceToDevice, nullptr));
-    HIP_TRY(hipMemcpyAsync(h + oPrev, d + oPrev, L.off - oPrev, hipMemcpyDeviceToHost, nullptr));
-    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipMemcpyAsync(h + oPrev, d + oPrev, L.off - oPrev, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     if ((rc = match_error((const int*)(h + oErr), s, "windowed matcher", mayRetry))) return rc;
     memcpy(prev_xy, h + oPrev, (size_t)n1 * 8);
     memcpy(matches12, h + oM, (size_t)n1 * 4);
@@ -1364,7 +1374,8 @@ static int match_projected_once(orb_ctx* c, int mode, const float* u, const floa
     const size_t oL0 = L.add((size_t)nq * 4), oL1 = L.add((size_t)nq * 4), oA = L.add((size_t)nq * 4);
     const size_t oQ = L.add((size_t)nq * 32), oObs = L.add((size_t)nq);
     const size_t oK2 = L.add((size_t)n2 * sizeof(orb_keypoint)), oD2 = L.add((size_t)n2 * 32), oOcc = L.add((size_t)n2);
-    const size_t oM = L.add((size_t)n2 * 4), oNm = L.add(4), oErr = L.add(8);  // outputs
+    const size_t oErr = L.add(8);                                             // error words: zero in, fetched with the outputs
+    const size_t oM = L.add((size_t)n2 * 4), oNm = L.add(4);                  // outputs
     if ((rc = ensure_block(s, L.off))) return rc;
     uint8_t* h = (uint8_t*)s->blockHost;
     uint8_t* d = (uint8_t*)s->blockDev;
@@ -1379,17 +1390,19 @@ static int match_projected_once(orb_ctx* c, int mode, const float* u, const floa
     memcpy(h + oK2, k2, (size_t)n2 * sizeof(orb_keypoint));
     memcpy(h + oD2, d2, (size_t)n2 * 32);
     if (occupied2) memcpy(h + oOcc, occupied2, (size_t)n2);
-    hipStream_t st = nullptr;
+    memset(h + oErr, 0, 8);
+    hipStream_t st = (hipStream_t)orb_ctx_stream(c);
+    int* const errw = (int*)(d + oErr);
+    B.poolUsed = (unsigned*)errw + 1;
     HIP_TRY(hipMemcpyAsync(d, h, oM, hipMemcpyHostToDevice, st));
     const GridGeom G = grid_geom(c, img_w, img_h);
     hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, st, (const orb_keypoint*)(d + oK2), (const int*)nullptr, n2, n2,
-                       G, B, (int*)s->err + 2, -1);
+                       G, B, errw, -1);
     if ((rc = check_match_launch())) return rc;
-    HIP_TRY(hipMemsetAsync(B.poolUsed, 0, 4, st));
     hipLaunchKernelGGL(k_match_lists<true>, dim3((nq + 3) / 4, 1), dim3(256), 0, st, (const orb_keypoint*)nullptr,
                        (const uint8_t*)(d + oQ), (const int*)nullptr, nq, nq, (const float*)nullptr, 0.f,
                        (const float*)(d + oU), (const float*)(d + oV), (const float*)(d + oR), (const int*)(d + oL0),
-                       (const int*)(d + oL1), (const uint8_t*)(d + oD2), n2, G, orb_ctx_quirks(c), B, (int*)s->err + 2);
+                       (const int*)(d + oL1), (const uint8_t*)(d + oD2), n2, G, orb_ctx_quirks(c), B, errw);
     if ((rc = check_match_launch())) return rc;
     static const bool inOrder = getenv("ORBHIP_MATCH_IN_ORDER") != nullptr;
     const bool par = !inOrder && nq <= M_PAR_MAXKP && n2 <= M_PAR_MAXKP;
@@ -1399,10 +1412,9 @@ static int match_projected_once(orb_ctx* c, int mode, const float* u, const floa
                        (const int*)nullptr, n2, n2, (float*)nullptr, (int*)nullptr, (uint8_t*)s->binOf,
                        (const float*)(d + oA), qobs ? (const uint8_t*)(d + oObs) : (const uint8_t*)nullptr,
                        occupied2 ? (const uint8_t*)(d + oOcc) : (const uint8_t*)nullptr, (int*)(d + oM), nnratio, th_high,
-                       check_ori, B, (int*)(d + oNm), (int*)s->err + 2);
+                       check_ori, B, (int*)(d + oNm), errw);
     if ((rc = check_match_launch())) return rc;
-    HIP_TRY(hipMemcpyAsync(d + oErr, (int*)s->err + 2, 8, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(h + oM, d + oM, L.off - oM, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h + oErr, d + oErr, L.off - oErr, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if ((rc = match_error((const int*)(h + oErr), s, "projected matcher", mayRetry))) return rc;
     memcpy(match2, h + oM, (size_t)n2 * 4);
@@ -1477,7 +1489,8 @@ extern "C" int orb_match_best(orb_ctx* c, const float* u, const float* v, const 
     const size_t oU = L.add((size_t)nq * 4), oV = L.add((size_t)nq * 4), oR = L.add((size_t)nq * 4);
     const size_t oL0 = L.add((size_t)nq * 4), oL1 = L.add((size_t)nq * 4), oQ = L.add((size_t)nq * 32);
     const size_t oK2 = L.add((size_t)n2 * sizeof(orb_keypoint)), oD2 = L.add((size_t)n2 * 32), oSig = L.add(256 * 4);
-    const size_t oIdx = L.add((size_t)nq * 4), oDist = L.add((size_t)nq * 4), oErr = L.add(8);  // outputs
+    const size_t oErr = L.add(8);  // error words: zero in, fetched with the outputs
+    const size_t oIdx = L.add((size_t)nq * 4), oDist = L.add((size_t)nq * 4);  // outputs
     if ((rc = ensure_block(s, L.off))) return rc;
     uint8_t* h = (uint8_t*)s->blockHost;
     uint8_t* d = (uint8_t*)s->blockDev;
@@ -1490,19 +1503,21 @@ extern "C" int orb_match_best(orb_ctx* c, const float* u, const float* v, const 
     memcpy(h + oK2, k2, (size_t)n2 * sizeof(orb_keypoint));
     memcpy(h + oD2, d2, (size_t)n2 * 32);
     if (ns) memcpy(h + oSig, inv_level_sigma2, (size_t)ns * 4);
-    hipStream_t st = nullptr;
+    memset(h + oErr, 0, 8);
+    hipStream_t st = (hipStream_t)orb_ctx_stream(c);
+    int* const errw = (int*)(d + oErr);
+    B.poolUsed = (unsigned*)errw + 1;
     HIP_TRY(hipMemcpyAsync(d, h, oIdx, hipMemcpyHostToDevice, st));
     const GridGeom G = grid_geom(c, img_w, img_h);
     hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, st, (const orb_keypoint*)(d + oK2), (const int*)nullptr, n2, n2,
-                       G, B, (int*)s->err + 2, -1);
+                       G, B, errw, -1);
     if ((rc = check_match_launch())) return rc;
     hipLaunchKernelGGL(k_match_best, dim3((nq + 3) / 4), dim3(256), 0, st, (const float*)(d + oU), (const float*)(d + oV),
                        (const float*)(d + oR), (const int*)(d + oL0), (const int*)(d + oL1), (const uint8_t*)(d + oQ), nq,
                        (const uint8_t*)(d + oD2), ns ? (const float*)(d + oSig) : (const float*)nullptr, ns, chi2_max, th, G,
                        orb_ctx_quirks(c), B, (int*)(d + oIdx), (int*)(d + oDist));
     if ((rc = check_match_launch())) return rc;
-    HIP_TRY(hipMemcpyAsync(d + oErr, (int*)s->err + 2, 8, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(h + oIdx, d + oIdx, L.off - oIdx, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h + oErr, d + oErr, L.off - oErr, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if ((rc = match_error((const int*)(h + oErr), s, "orb_match_best", false))) return rc;
     memcpy(best_idx, h + oIdx, (size_t)nq * 4);

@@ -35,7 +35,6 @@ extern "C" int orb_debug_quadtree_profile(unsigned long long* out, int clear) {
 #endif
 
 #define QT_MAX_THREADS 1024
-#define QT_CELLS_IN_FLIGHT 8   // cells whose loads a lane group of the counting pass has under way at once
 #define QT_LDS_KEYS_MAX 4096
 #define QT_STATIC_LDS 1024     // bound on sizeof(QtShared)
 
@@ -135,7 +134,9 @@ static __device__ __forceinline__ void qt_work_global(QtWork* w, const OrbGeom* 
     w->scanC = p;
 }
 
-// One (frame, level): `wg` is its number in the level-major order of the launch.
+// One (frame, level): `wg` is its number in the level-major order of the launch.  F: cells whose loads a lane group
+// of the counting pass has under way at once (twice that with the round asked for ahead).
+template <int F>
 static __device__ __forceinline__ void qt_one(const OrbGeom* __restrict__ g, const QtLaunch& q, int wg, int frame0, int nframes,
                                               const uint32_t* __restrict__ cellKeys, const int* __restrict__ cellCount,
                                               const uint32_t* __restrict__ codeTab, unsigned long long* __restrict__ sortBuf,
@@ -168,48 +169,83 @@ static __device__ __forceinline__ void qt_one(const OrbGeom* __restrict__ g, con
     if (2 * nb + 1 <= q.regionInts) {
         int* start = s_region;
         uint32_t* best = (uint32_t*)(s_region + nb + 1);
+        // Four lanes per cell, four key slots per lane: a cell's first 16 slots are read whether or not they hold
+        // keys (slots are 16-byte aligned, at least 16 long, and share a cache line or two), so that the load does
+        // not wait for the cell's count.  F cells per lane group are under way at once, the first round's loads are
+        // issued before the histogram is cleared, and the next round's counts and slots are asked for before this
+        // round's keys are looked at: a level costs about three dependent memory round trips (counts and slots;
+        // path words; the next round hides behind them) instead of three per round.  Keys beyond a cell's first
+        // 16 follow one by one (rare).
+        const int shiftB = 2 * (ORB_CODE_DEPTH - Db);
+        const int sub = t & 3, ngrp = T >> 2;
+        auto fetch = [&](int c0, int (&cnt)[F], uint4 (&slot)[F]) {
+#pragma unroll
+            for (int u = 0; u < F; u++) {
+                const int c = c0 + u * ngrp;
+                const bool in = c < nCells;
+                cnt[u] = in ? cc[c] : 0;
+                slot[u] = in ? *(const uint4*)(lck + (int64_t)c * cellCap + 4 * sub) : make_uint4(0u, 0u, 0u, 0u);
+            }
+        };
+        auto add_key = [&](uint32_t rank, uint32_t key, uint32_t code) {
+            const uint32_t prio = ((key >> 16) << 24) | (~rank & 0xffffffu);  // = qt_entry_prio of the key's sort entry
+            atomicAdd(&start[code >> shiftB], 1);
+            atomicMax(&best[code >> shiftB], prio);
+        };
+        int cnt[F];
+        uint4 slot[F];
+        int c0 = t >> 2;
+        fetch(c0, cnt, slot);
         for (int b = t; b < nb; b += T) {
             start[b] = 0;
             best[b] = 0u;
         }
         if (t == 0) start[nb] = 0;
         __syncthreads();
-        // Eight lanes per cell: a cell's keys are consecutive words, and most cells hold fewer than eight.  Eight
-        // cells are in flight per lane group (counts, then first keys, then path words: three dependent loads
-        // whose latency would otherwise be paid cell after cell); keys beyond a cell's first eight follow.
-        const int shiftB = 2 * (ORB_CODE_DEPTH - Db);
-        const int sub = t & 7, ngrp = T >> 3;
-        auto count_key = [&](int c, int k, uint32_t key, int bx, int by) {
-            const uint32_t code = codeX[bx + (int)(key & 0xff)] | codeY[by + (int)((key >> 8) & 0xff)];
-            const uint32_t rank = (uint32_t)(c * cellCap + k);
-            const uint32_t prio = ((key >> 16) << 24) | (~rank & 0xffffffu);  // = qt_entry_prio of the key's sort entry
-            atomicAdd(&start[code >> shiftB], 1);
-            atomicMax(&best[code >> shiftB], prio);
-        };
-        for (int c0 = t >> 3; c0 < nCells; c0 += QT_CELLS_IN_FLIGHT * ngrp) {
-            int cnt[QT_CELLS_IN_FLIGHT], bx[QT_CELLS_IN_FLIGHT], by[QT_CELLS_IN_FLIGHT];
-            uint32_t key[QT_CELLS_IN_FLIGHT];
+        while (c0 < nCells) {
+            int cntN[F];
+            uint4 slotN[F];
+            fetch(c0 + F * ngrp, cntN, slotN);
+            uint32_t key[F][4], code[F][4];
 #pragma unroll
-            for (int u = 0; u < QT_CELLS_IN_FLIGHT; u++) {
+            for (int u = 0; u < F; u++) {
                 const int c = c0 + u * ngrp;
-                cnt[u] = c < nCells ? cc[c] : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < QT_CELLS_IN_FLIGHT; u++) {
-                const int c = c0 + u * ngrp;
-                key[u] = sub < cnt[u] ? lck[(int64_t)c * cellCap + sub] : 0u;
                 const int ci = (int)orb_div((unsigned)c, (unsigned)L.nCols, L.nColsMagic), cj = c - ci * L.nCols;
-                bx[u] = 3 + cj * L.wCell;  // relative to the 16-pixel border, as :864-865
-                by[u] = 3 + ci * L.hCell;
+                const int bx = 3 + cj * L.wCell, by = 3 + ci * L.hCell;  // relative to the 16-pixel border, as :864-865
+                const uint32_t k4[4] = {slot[u].x, slot[u].y, slot[u].z, slot[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    // (a slot without a key holds anything, and cells past the last lie outside the tables: such
+                    // slots read the tables' first words)
+                    const bool has = 4 * sub + j < cnt[u];
+                    key[u][j] = k4[j];
+                    code[u][j] = codeX[has ? bx + (int)(k4[j] & 0xff) : 0] | codeY[has ? by + (int)((k4[j] >> 8) & 0xff) : 0];
+                }
             }
 #pragma unroll
-            for (int u = 0; u < QT_CELLS_IN_FLIGHT; u++)
-                if (sub < cnt[u]) count_key(c0 + u * ngrp, sub, key[u], bx[u], by[u]);
+            for (int u = 0; u < F; u++) {
+                const uint32_t rank0 = (uint32_t)((c0 + u * ngrp) * cellCap + 4 * sub);
 #pragma unroll
-            for (int u = 0; u < QT_CELLS_IN_FLIGHT; u++) {
+                for (int j = 0; j < 4; j++)
+                    if (4 * sub + j < cnt[u]) add_key(rank0 + (uint32_t)j, key[u][j], code[u][j]);
+            }
+#pragma unroll
+            for (int u = 0; u < F; u++) {
+                if (cnt[u] <= 16) continue;
                 const int c = c0 + u * ngrp;
-                for (int k = sub + 8; k < cnt[u]; k += 8) count_key(c, k, lck[(int64_t)c * cellCap + k], bx[u], by[u]);
+                const int ci = (int)orb_div((unsigned)c, (unsigned)L.nCols, L.nColsMagic), cj = c - ci * L.nCols;
+                const int bx = 3 + cj * L.wCell, by = 3 + ci * L.hCell;
+                for (int k = 16 + sub; k < cnt[u]; k += 4) {
+                    const uint32_t kk = lck[(int64_t)c * cellCap + k];
+                    add_key((uint32_t)(c * cellCap + k), kk, codeX[bx + (int)(kk & 0xff)] | codeY[by + (int)((kk >> 8) & 0xff)]);
+                }
             }
+#pragma unroll
+            for (int u = 0; u < F; u++) {
+                cnt[u] = cntN[u];
+                slot[u] = slotN[u];
+            }
+            c0 += F * ngrp;
         }
         __syncthreads();
         QT_STAMP(1);
@@ -311,7 +347,9 @@ static __device__ __forceinline__ void qt_one(const OrbGeom* __restrict__ g, con
     if (t == 0) levelCount[frame * nlevels + level] = count;
 }
 
-__global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __restrict__ g, const QtLaunch q, int frame0, int nframes,
+// MAXT = 512: up to 256 registers per lane (nothing spills); 1024 for the full workgroups of large frames.
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_quadtree(const OrbGeom* __restrict__ g, const QtLaunch q, int frame0, int nframes,
                                                         const uint32_t* __restrict__ cellKeys,
                                                         const int* __restrict__ cellCount,
                                                         const uint32_t* __restrict__ codeTab,
@@ -326,14 +364,14 @@ __global__ __launch_bounds__(QT_MAX_THREADS) void k_quadtree(const OrbGeom* __re
     unsigned long long* const s_keys = s_dyn;
     int* const s_region = (int*)(s_dyn + q.ldsKeys);
     if (q.pass != 2) {
-        qt_one(g, q, (int)blockIdx.x, frame0, nframes, cellKeys, cellCount, codeTab, sortBuf, nodes, ints, selXY, selScore, levelCount,
+        qt_one<(MAXT <= 512 ? 4 : 2)>(g, q, (int)blockIdx.x, frame0, nframes, cellKeys, cellCount, codeTab, sortBuf, nodes, ints, selXY, selScore, levelCount,
                levelKeys, retry, error, sh, s_keys, s_region);
         return;
     }
     // second pass: the levels the first pass listed (its launch is complete: same stream), a few per workgroup
     const int listed = retry[0];
     for (int i = (int)blockIdx.x; i < listed; i += (int)gridDim.x) {
-        qt_one(g, q, retry[1 + i], frame0, nframes, cellKeys, cellCount, codeTab, sortBuf, nodes, ints, selXY, selScore, levelCount,
+        qt_one<(MAXT <= 512 ? 4 : 2)>(g, q, retry[1 + i], frame0, nframes, cellKeys, cellCount, codeTab, sortBuf, nodes, ints, selXY, selScore, levelCount,
                levelKeys, retry, error, sh, s_keys, s_region);
         __syncthreads();
     }
@@ -393,7 +431,7 @@ static int qt_launch(const OrbBatch& b, bool bigFrames, int pass) {
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (dev < 0 || dev >= 64 || !asked[dev].load(std::memory_order_acquire)) {
-            hipError_t ea = hipFuncSetAttribute((const void*)k_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - QT_STATIC_LDS);
+            hipError_t ea = hipFuncSetAttribute((const void*)k_quadtree<QT_MAX_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - QT_STATIC_LDS);
             if (ea != hipSuccess) {
                 orb_set_error("quadtree: %zu bytes of LDS per workgroup refused: %s", lds, hipGetErrorString(ea));
                 return ORB_ERR_HIP;
@@ -411,7 +449,7 @@ static int qt_launch(const OrbBatch& b, bool bigFrames, int pass) {
             return ORB_ERR_HIP;
         }
     }
-    hipLaunchKernelGGL(k_quadtree, dim3(pass == 2 ? std::min(all, 1024) : all), dim3(threads), lds, (hipStream_t)b.stream, b.d_geom, q,
+    hipLaunchKernelGGL(bigFrames ? k_quadtree<QT_MAX_THREADS> : k_quadtree<512>, dim3(pass == 2 ? std::min(all, 1024) : all), dim3(threads), lds, (hipStream_t)b.stream, b.d_geom, q,
                        b.frame0, b.nframes, b.d_cellKeys, b.d_cellCount, b.d_codeTab, b.d_sort, b.d_nodes, b.d_ints, b.d_selXY, b.d_selScore, b.d_levelCount,
                        b.d_levelKeys, retry, b.d_error);
     hipError_t e = hipGetLastError();

@@ -232,6 +232,7 @@ int orb_ctx_device(const orb_ctx* c) { return c->prm.device; }
 unsigned orb_ctx_quirks(const orb_ctx* c) { return c->prm.quirks; }
 int orb_ctx_max_batch(const orb_ctx* c) { return c->prm.max_batch; }
 void** orb_ctx_match_state(orb_ctx* c) { return &c->matchState; }
+void* orb_ctx_stream(orb_ctx* c) { return (void*)c->stream; }
 void** orb_ctx_bow_state(orb_ctx* c) { return &c->bowState; }
 int orb_ctx_get_bounds(const orb_ctx* c, float b[4]) {
     if (c->haveBounds) memcpy(b, c->bounds, sizeof(c->bounds));
@@ -594,6 +595,9 @@ static int compute_geom(orb_ctx* c, int w, int h) {
                       (1 << (ORB_CODE_DEPTH - 1)) + 2 * ORB_BORDER);
         return ORB_ERR_UNSUPPORTED;
     }
+    // a cell's slots start 16-byte aligned and number at least 16: the quadtree's counting pass reads the first 16
+    // of every cell as four-word loads
+    cellCap = std::max(16, (cellCap + 3) & ~3);
     for (int l = 0; l < g.nlevels; l++) {
         if ((int64_t)g.lv[l].nCols * g.lv[l].nRows * cellCap > (int64_t)1 << 24) {
             orb_set_error("frame too large: level %d needs more than 2^24 key ranks", l);

@@ -50,10 +50,25 @@ static inline int qt_host_fetch_add(int* p, int v) {
 // boundaries into g_qtProfile (kernels_quadtree.hip, read back with orb_debug_quadtree_profile).
 #if defined(QT_PROFILE) && !defined(ORB_HOST_EMU)
 extern __device__ unsigned long long g_qtProfile[32];
+#ifdef QT_PROFILE_SUM
+// ... or, with -DQT_PROFILE_SUM as well, every workgroup adds the engine cycles since its previous stamp to
+// g_qtProfile[k] (and counts itself in g_qtProfile[k + 16] for k < 16): where the workgroups of a full launch
+// spend their time
+static __shared__ unsigned long long g_qtPrev;
+#define QT_STAMP(k)                                                                                   \
+    do {                                                                                              \
+        if (threadIdx.x == 0) {                                                                       \
+            const unsigned long long now_ = clock64();                                                \
+            if ((k) != 0) atomicAdd(&g_qtProfile[k], now_ - g_qtPrev);                                \
+            g_qtPrev = now_;                                                                          \
+        }                                                                                             \
+    } while (0)
+#else
 #define QT_STAMP(k)                                                                   \
     do {                                                                              \
         if (blockIdx.x == 0 && threadIdx.x == 0) g_qtProfile[k] = wall_clock64();     \
     } while (0)
+#endif
 #define QT_COUNT(k)                                                       \
     do {                                                                  \
         if (blockIdx.x == 0 && threadIdx.x == 0) g_qtProfile[k] += 1ull;  \
