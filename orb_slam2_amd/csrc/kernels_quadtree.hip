@@ -78,7 +78,7 @@ static __device__ __forceinline__ int qt_finish(const OrbGeom* g, const OrbLevel
         if (t == 0) atomicOr(error, 32);
         count = L.outCap;
     }
-    qt_select_all(sp, list, count, w.scanA, sh);
+    qt_select_all(sp, list, count, w.scanA, sh, L.nIni);
     QT_STAMP(6);
     for (int i = t; i < count; i += T) {
         const int rank = w.scanA[i];
@@ -136,6 +136,8 @@ static __device__ __forceinline__ void qt_work_global(QtWork* w, const OrbGeom* 
 
 // One (frame, level): `wg` is its number in the level-major order of the launch.  F: cells whose loads a lane group
 // of the counting pass has under way at once (twice that with the round asked for ahead).
+// (The node scratch lies in LDS or in global memory, so the list accesses are flat instructions.  An instance that
+// knew it to be in LDS ran slower: 0.119 against 0.108 ms at 512 frames.)
 template <int F>
 static __device__ __forceinline__ void qt_one(const OrbGeom* __restrict__ g, const QtLaunch& q, int wg, int frame0, int nframes,
                                               const uint32_t* __restrict__ cellKeys, const int* __restrict__ cellCount,
@@ -347,7 +349,8 @@ static __device__ __forceinline__ void qt_one(const OrbGeom* __restrict__ g, con
     if (t == 0) levelCount[frame * nlevels + level] = count;
 }
 
-// MAXT = 512: up to 256 registers per lane (nothing spills); 1024 for the full workgroups of large frames.
+// MAXT = 512: up to 168 registers per lane (three wavefronts per SIMD, as many as the LDS blocks allow anyway);
+// 1024: the full workgroups of large frames.
 template <int MAXT>
 __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_quadtree(const OrbGeom* __restrict__ g, const QtLaunch q, int frame0, int nframes,
                                                         const uint32_t* __restrict__ cellKeys,
@@ -419,7 +422,10 @@ static int qt_launch(const OrbBatch& b, bool bigFrames, int pass) {
     const int threads = bigFrames ? 1024 : b.nframes < ORB_FEW_FRAMES ? 512 : qt_large_launch(b.nframes * g.nlevels) ? 128 : 256;
     QtLaunch q = qt_plan(g, bigFrames, pass);
     q.nframesMagic = orb_div_magic((uint32_t)b.nframes, (uint64_t)b.nframes * q.nlevels);
-    const size_t lds = (size_t)q.ldsKeys * 8 + (size_t)q.regionInts * 4;
+    size_t lds = (size_t)q.ldsKeys * 8 + (size_t)q.regionInts * 4;
+#ifdef QT_PROFILE
+    if (const char* pad = getenv("ORBHIP_QT_LDS_PAD")) lds += (size_t)atoi(pad);  // fewer workgroups per CU, to see what they cost each other
+#endif
     if (lds + QT_STATIC_LDS > 160 * 1024) {
         orb_set_error("internal: quadtree LDS block of %zu bytes", lds);
         return ORB_ERR_UNSUPPORTED;

@@ -390,6 +390,7 @@ struct QtSortedSpace {
     QT_MFN int cell_lo(int, int) const { return 0; }
     QT_MFN int items(const OrbNode& nd) const { return nd.hi - nd.lo; }
     QT_MFN uint32_t prio_at(const OrbNode& nd, int i) const { return qt_entry_prio(s[nd.lo + i]); }
+    static constexpr bool kWinnerTable = false;
 };
 
 // QtHistSpace: no key array at all.  The keys are counted into buckets = quadtree cells of depth Db (bucket number
@@ -451,6 +452,37 @@ struct QtHistSpace {
         return d < Db ? 1 << (2 * (Db - d)) : 1;
     }
     QT_MFN uint32_t prio_at(const OrbNode& nd, int i) const { return best[QT_B0(nd) + i]; }  // 0: empty bucket
+    // A node of depth d < Db is one quadtree cell = an aligned run of 4^(Db - d) buckets, so the winners of all
+    // possible nodes form a pyramid over best[]: level k holds the largest entry of every aligned run of 4^k
+    // buckets.  Built once the distribution is over (start[] is free then and holds the levels one after the
+    // other: fewer than nb / 3 + Db words for nb = nIni 4^Db buckets), it turns a node's winner into one read.
+    static constexpr bool kWinnerTable = true;
+    QT_MFN int winner_levels() const { return Db; }
+    QT_MFN void winner_table_build(int nIni) const {
+        const int T = QT_NT, t = QT_TID;
+        uint32_t* const tab = (uint32_t*)start;
+        const uint32_t* src = best;
+        int o = 0;
+        for (int k = 1; k <= Db; k++) {
+            const int m = nIni << (2 * (Db - k));
+            for (int i = t; i < m; i += T) {
+                const uint32_t a = src[4 * i], b = src[4 * i + 1], c = src[4 * i + 2], d = src[4 * i + 3];
+                const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+                tab[o + i] = ab > cd ? ab : cd;
+            }
+            QT_BARRIER();
+            src = tab + o;
+            o += m;
+        }
+    }
+    QT_MFN uint32_t winner_of(const OrbNode& nd, int nIni) const {
+        const int d = QT_DEPTH(nd), b0 = QT_B0(nd);
+        if (d >= Db) return best[b0];
+        const int k = Db - d;
+        // level k starts behind levels 1 .. k - 1: nIni (4^(Db-1) + .. + 4^(Db-k+1)) words
+        const int o = (int)((((long long)nIni << (2 * Db)) - ((long long)nIni << (2 * (Db - k + 1)))) / 3);
+        return ((const uint32_t*)start)[o + (b0 >> (2 * k))];
+    }
 };
 
 QT_FN int qt_child_flags(int q, int cnt, int n3quirk) {
@@ -1023,8 +1055,16 @@ QT_FN void qt_sort_keys(const unsigned long long* tmp, unsigned long long* sorte
 // wavefront.
 #define QT_SELECT_SERIAL 64
 template <class Space>
-QT_FN void qt_select_all(const Space& sp, const OrbNode* list, int count, int* outRank, QtShared* sh) {
+QT_FN void qt_select_all(const Space& sp, const OrbNode* list, int count, int* outRank, QtShared* sh, int nIni = 0) {
     const int T = QT_NT, t = QT_TID;
+    if constexpr (Space::kWinnerTable) {
+        if (nIni > 0) {
+            sp.winner_table_build(nIni);
+            for (int i = t; i < count; i += T) outRank[i] = (int)(~sp.winner_of(list[i], nIni) & 0xffffffu);
+            QT_BARRIER();
+            return;
+        }
+    }
     if (t == 0) sh->nBig = 0;
     QT_BARRIER();
     for (int i = t; i < count; i += T) {

@@ -72,7 +72,7 @@ extern "C" int qt_emu_distribute_hist(const int* xs, const int* ys, const int* s
     *err = n > 0 ? sh.err : 0;
     if (n > 0 && sh.deeper) return -1;
     std::vector<int> ranks(cnt > 0 ? cnt : 1);
-    if (cnt > 0) qt_select_all(sp, out, cnt, ranks.data(), &sh);
+    if (cnt > 0) qt_select_all(sp, out, cnt, ranks.data(), &sh, nIni);  // (winners from the table over best[], as the device)
     for (int i = 0; i < cnt && i < outCap; i++) outRank[i] = (ranks[i] - 1) / 3;
     return cnt;
 }
