@@ -251,7 +251,7 @@ static __device__ __forceinline__ void qt_one(const OrbGeom* __restrict__ g, con
         }
         __syncthreads();
         QT_STAMP(1);
-        qt_scan(start, nb, &sh);
+        qt_scan_buckets(start, nb, &sh);  // (start = the dynamic LDS block's first word: 16-byte aligned)
         const int n = start[nb];
         if (t == 0) levelKeys[frame * nlevels + level] = n;
         if (n > L.keyCap) {  // cannot happen: keyCap is the 2x2-block bound summed over the cells
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(3, 4))) vo
                                                         int* __restrict__ retry, int* __restrict__ error) {
     static_assert(sizeof(QtShared) <= QT_STATIC_LDS, "QtShared outgrew its bound");
     __shared__ QtShared sh;
-    extern __shared__ unsigned long long s_dyn[];  // q.ldsKeys entries, then q.regionInts ints
+    extern __shared__ __align__(16) unsigned long long s_dyn[];  // q.ldsKeys entries, then q.regionInts ints
     unsigned long long* const s_keys = s_dyn;
     int* const s_region = (int*)(s_dyn + q.ldsKeys);
     if (q.pass != 2) {
