@@ -1136,7 +1136,19 @@ static int extract_batch_begin(orb_ctx* c, const uint8_t* const* imgs, int n, in
         for (int i = 1; i <= parts; i++) gs[i] = first + (int)((int64_t)(n - first) * (i - 1) / std::max(1, parts - 1));
         gs[parts] = n;
     }
-    if (pinned) {
+    // A few frames (the reference's one-frame-per-call use) are fetched by a kernel that reads the page-locked memory
+    // over the link: a DMA copy of one 640x480 frame takes 11 us and the first kernel behind it starts 12 us later,
+    // the kernel takes 8 us and the next one follows at once.  ORBHIP_UPLOAD_DMA=1 keeps the copy engine.
+    static const bool uploadDma = getenv("ORBHIP_UPLOAD_DMA") != nullptr;
+    auto fetch_by_kernel = [&](const uint8_t* hostSrc, int srcStride, int64_t srcFrame, int f0, int count) -> int {
+        uint8_t* dsrc = nullptr;  // the frames as the device addresses them
+        HIP_TRY(hipHostGetDevicePointer((void**)&dsrc, (void*)hostSrc, 0));
+        return orb_launch_realign(dsrc, w, h, srcStride, srcFrame, (uint8_t*)c->dInput.p + (size_t)f0 * fstride, dstride, count, c->stream);
+    };
+    if (pinned && few && !uploadDma) {
+        for (int f = 0; f < n; f++)
+            if ((rc = fetch_by_kernel(imgs[f], stride, 0, f, 1))) return rc;
+    } else if (pinned) {
         // Page-locked frames go to the device from where they are: no staging copy on the host (which runs at the
         // host memory's rate, and at that rate for all contexts of a node together).  Frames that follow each other
         // at a fixed distance travel as one copy per frame group, the later groups' first (those groups extract while
@@ -1190,7 +1202,8 @@ static int extract_batch_begin(orb_ctx* c, const uint8_t* const* imgs, int n, in
         if (few) {
             // a few frames (the reference's one-frame-per-call use): one host thread, one copy
             stage_frames(0, n);
-            HIP_TRY(hipMemcpyAsync(c->dInput.p, c->pinIn.p, (size_t)n * fstride, hipMemcpyHostToDevice, c->stream));
+            if (uploadDma) HIP_TRY(hipMemcpyAsync(c->dInput.p, c->pinIn.p, (size_t)n * fstride, hipMemcpyHostToDevice, c->stream));
+            else if ((rc = fetch_by_kernel((const uint8_t*)c->pinIn.p, dstride, fstride, 0, n))) return rc;
         } else {
             const int per = (int)std::max<int64_t>(1, std::min<int64_t>(n, ORB_STAGE_SLICE_BYTES / fstride));
             int sl0[ORB_MAX_STAGE_SLICES], sl1[ORB_MAX_STAGE_SLICES], slEv[ORB_MAX_STAGE_SLICES], nsl = 0;
