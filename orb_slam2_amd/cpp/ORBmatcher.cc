@@ -1,6 +1,7 @@
 // Drop-in ORBmatcher over the C ABI of liborbhip (see ORBmatcher.h).
 #include "ORBmatcher.h"
 
+#include <algorithm>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -72,6 +73,9 @@ int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, 
     std::vector<float> u, v, radius, qangle;
     std::vector<int> lmin, lmax, src;
     std::vector<unsigned char> qdesc, qobs;
+    const size_t most = (size_t)std::max(LastFrame.N, 0);
+    u.reserve(most), v.reserve(most), radius.reserve(most), qangle.reserve(most);
+    lmin.reserve(most), lmax.reserve(most), src.reserve(most), qobs.reserve(most), qdesc.reserve(most * 32);
     for (int i = 0; i < LastFrame.N; i++) {
         MapPoint* pMP = LastFrame.mvpMapPoints[i];
         if (!pMP) continue;
@@ -173,6 +177,9 @@ int ORBmatcher::SearchByProjection(Frame& F, const std::vector<MapPoint*>& vpMap
     std::vector<float> u, v, radius;
     std::vector<int> lmin, lmax, src;
     std::vector<unsigned char> qdesc, qobs;
+    const size_t most = vpMapPoints.size();
+    u.reserve(most), v.reserve(most), radius.reserve(most);
+    lmin.reserve(most), lmax.reserve(most), src.reserve(most), qobs.reserve(most), qdesc.reserve(most * 32);
     for (size_t iMP = 0; iMP < vpMapPoints.size(); iMP++) {
         MapPoint* pMP = vpMapPoints[iMP];
         if (!pMP->mbTrackInView) continue;

@@ -107,14 +107,17 @@ static __device__ __forceinline__ uint32_t list_entry(const MatchBuffers& B, con
 // keypoints that fall outside the grid are left out.  maxOctave >= 0 also leaves out the keypoints of coarser
 // levels: a search whose every query asks for levels up to maxOctave only (SearchForInitialization: level 0,
 // src/ORBmatcher.cc:41-46) never looks at them, and a 2000-feature frame has 434 keypoints on level 0.
-__global__ __launch_bounds__(256) void k_grid_build(const orb_keypoint* __restrict__ k2all, const int* __restrict__ n2s,
+// (1024 threads: a call on one pair of frames is a single workgroup, whose every phase is a few dependent steps
+// per thread; with 256 threads the kernel took 18 us for 1000 keypoints.)
+#define GB_THREADS 1024
+__global__ __launch_bounds__(GB_THREADS) void k_grid_build(const orb_keypoint* __restrict__ k2all, const int* __restrict__ n2s,
                                                     int n2const, int stride2, GridGeom G, MatchBuffers B,
                                                     int* __restrict__ error, int maxOctave) {
     __shared__ uint32_t s_sorted[M_MAXKP];
     __shared__ uint32_t s_key[M_MAXKP];
     __shared__ int s_start[M_CELLS + 1];
     __shared__ int s_cursor[M_CELLS];
-    __shared__ int s_part[4];
+    __shared__ int s_part[GB_THREADS / 64];
     __shared__ int s_big[M_MAXKP / 32];
     __shared__ int s_nBig;
     const int pair = blockIdx.x, t = threadIdx.x;
@@ -123,14 +126,14 @@ __global__ __launch_bounds__(256) void k_grid_build(const orb_keypoint* __restri
     const int n2 = n2s ? n2s[pair] : n2const;
     if (n2 > stride2 || n2 > M_MAXKP || n2 < 0) {
         if (t == 0) atomicOr(error, M_ERR_LIMIT);
-        for (int c = t; c <= M_CELLS; c += 256) cellStart[c] = 0;  // an empty grid: the later kernels find nothing
+        for (int c = t; c <= M_CELLS; c += GB_THREADS) cellStart[c] = 0;  // an empty grid: the later kernels find nothing
         return;
     }
     // Counting sort by bucket: histogram, prefix sum, scatter; a bucket's few entries are then put in
     // index order by one thread (the scatter's order depends on how the atomics were served).
-    for (int c = t; c <= M_CELLS; c += 256) s_start[c] = 0;
+    for (int c = t; c <= M_CELLS; c += GB_THREADS) s_start[c] = 0;
     __syncthreads();
-    for (int i = t; i < n2; i += 256) {
+    for (int i = t; i < n2; i += GB_THREADS) {
         const int px = (int)roundf(__fmul_rn(__fsub_rn(k2[i].x, G.minX), G.wInv));  // Frame::PosInGrid
         const int py = (int)roundf(__fmul_rn(__fsub_rn(k2[i].y, G.minY), G.hInv));
         uint32_t key = 0xFFFFFFFFu;
@@ -141,8 +144,9 @@ __global__ __launch_bounds__(256) void k_grid_build(const orb_keypoint* __restri
         s_key[i] = key;
     }
     __syncthreads();
-    {   // exclusive prefix sum of the M_CELLS counts: 12 consecutive buckets per thread, then across threads
-        const int per = M_CELLS / 256;  // 3072 / 256
+    {   // exclusive prefix sum of the M_CELLS counts: three consecutive buckets per thread, then across threads
+        constexpr int per = M_CELLS / GB_THREADS;
+        static_assert(per * GB_THREADS == M_CELLS, "buckets divide evenly among the threads");
         int v[per], sum = 0;
 #pragma unroll
         for (int j = 0; j < per; j++) {
@@ -166,17 +170,17 @@ __global__ __launch_bounds__(256) void k_grid_build(const orb_keypoint* __restri
             s_cursor[t * per + j] = run;
             run += v[j];
         }
-        if (t == 255) s_start[M_CELLS] = run;
+        if (t == GB_THREADS - 1) s_start[M_CELLS] = run;
     }
     __syncthreads();
-    for (int i = t; i < n2; i += 256) {
+    for (int i = t; i < n2; i += GB_THREADS) {
         const uint32_t key = s_key[i];
         if (key != 0xFFFFFFFFu) s_sorted[atomicAdd(&s_cursor[key >> 16], 1)] = key;
     }
     __syncthreads();
     if (t == 0) s_nBig = 0;
     __syncthreads();
-    for (int c = t; c < M_CELLS; c += 256) {
+    for (int c = t; c < M_CELLS; c += GB_THREADS) {
         const int lo = s_start[c], m = s_start[c + 1] - lo;
         if (m > 32) {  // crowded bucket: left to the whole workgroup below (at most M_MAXKP / 32 of them)
             s_big[atomicAdd(&s_nBig, 1)] = c;
@@ -195,23 +199,23 @@ __global__ __launch_bounds__(256) void k_grid_build(const orb_keypoint* __restri
     __syncthreads();
     for (int b = 0; b < s_nBig; b++) {  // rank sort through s_key, which is free again
         const int lo = s_start[s_big[b]], m = s_start[s_big[b] + 1] - lo;
-        for (int i = t; i < m; i += 256) {
+        for (int i = t; i < m; i += GB_THREADS) {
             const uint32_t x = s_sorted[lo + i];
             int r = 0;
             for (int j = 0; j < m; j++) r += s_sorted[lo + j] < x;
             s_key[r] = x;
         }
         __syncthreads();
-        for (int i = t; i < m; i += 256) s_sorted[lo + i] = s_key[i];
+        for (int i = t; i < m; i += GB_THREADS) s_sorted[lo + i] = s_key[i];
         __syncthreads();
     }
-    for (int c = t; c <= M_CELLS; c += 256) cellStart[c] = s_start[c];
+    for (int c = t; c <= M_CELLS; c += GB_THREADS) cellStart[c] = s_start[c];
     __syncthreads();
     const int nIn = s_start[M_CELLS];
     uint32_t* gS = B.gSorted + (int64_t)pair * stride2;
     float2* gXY = B.gXY + (int64_t)pair * stride2;
     uint8_t* gO = B.gOct + (int64_t)pair * stride2;
-    for (int p = t; p < nIn; p += 256) {
+    for (int p = t; p < nIn; p += GB_THREADS) {
         const uint32_t key = s_sorted[p];
         const orb_keypoint kp = k2[key & 0xFFFFu];
         gS[p] = key;
@@ -988,6 +992,7 @@ struct MatchState {
     size_t capLists = 0;    // list entries
     void* blockDev = nullptr;   // staging of the host-pointer entry points, see below
     void* blockHost = nullptr;
+    void* blockHostDev = nullptr;  // blockHost as the device addresses it
     size_t blockBytes = 0;
 };
 
@@ -1168,7 +1173,7 @@ static int match_window_batch(orb_ctx* c, int npairs, const orb_keypoint* d_k1, 
     }
     hipStream_t st = (hipStream_t)stream;
     const GridGeom G = grid_geom(c, img_w, img_h);
-    hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(256), 0, st, d_k2, d_n2, 0, stride2, G, B,
+    hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(GB_THREADS), 0, st, d_k2, d_n2, 0, stride2, G, B,
                        errw, 0);
     if ((rc = check_match_launch())) return rc;
     if (!blockErr) HIP_TRY(hipMemsetAsync(B.poolUsed, 0, 4, st));
@@ -1215,6 +1220,29 @@ struct Block {
 };
 }  // namespace
 
+// Transfers between the page-locked block and its device copy by a kernel that reads or writes the host memory over
+// the link: a call moves some tens of KB each way, for which the copy engine's start-up and the wait between it
+// and the next kernel (7 + 33 us in front of a projected search) cost more than the transfer.
+__global__ __launch_bounds__(256) void k_block_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, unsigned n16) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
+}
+// [off, off + bytes) of the block (offsets and sizes are multiples of 16, as Block::add lays them out)
+static int block_copy(MatchState* s, size_t off, size_t bytes, bool toDevice, hipStream_t st) {
+    if (!bytes) return ORB_OK;
+    static const bool dma = getenv("ORBHIP_UPLOAD_DMA") != nullptr;
+    uint8_t* const h = (uint8_t*)s->blockHostDev + off;
+    uint8_t* const d = (uint8_t*)s->blockDev + off;
+    if (dma || (bytes >> 4) > 0x7fffffffull) {
+        HIP_TRY(hipMemcpyAsync(toDevice ? (void*)d : (void*)((uint8_t*)s->blockHost + off), toDevice ? (const void*)((uint8_t*)s->blockHost + off) : (const void*)d,
+                               bytes, toDevice ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st));
+        return ORB_OK;
+    }
+    const unsigned n16 = (unsigned)(bytes >> 4);
+    hipLaunchKernelGGL(k_block_copy, dim3(std::min(1024u, (n16 + 255u) / 256u)), dim3(256), 0, st,
+                       (const uint4*)(toDevice ? h : d), (uint4*)(toDevice ? d : h), n16);
+    return check_match_launch();
+}
+
 static int ensure_block(MatchState* s, size_t bytes) {
     if (bytes <= s->blockBytes) return ORB_OK;
     HIP_TRY(hipDeviceSynchronize());
@@ -1224,6 +1252,7 @@ static int ensure_block(MatchState* s, size_t bytes) {
     s->blockBytes = 0;
     hipError_t e = hipMalloc(&s->blockDev, bytes);
     if (e == hipSuccess) e = hipHostMalloc(&s->blockHost, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&s->blockHostDev, s->blockHost, 0);
     if (e != hipSuccess) {
         orb_set_error("matcher staging (%zu bytes): %s", bytes, hipGetErrorString(e));
         return ORB_ERR_NOMEM;
@@ -1314,13 +1343,13 @@ static int match_window_once(orb_ctx* c, const orb_keypoint* k1, const uint8_t* 
     memcpy(h + oPrev, prev_xy, (size_t)n1 * 8);
     memset(h + oErr, 0, 8);
     hipStream_t st = (hipStream_t)orb_ctx_stream(c);
-    HIP_TRY(hipMemcpyAsync(d, h, oM, hipMemcpyHostToDevice, st));
+    if ((rc = block_copy(s, 0, oM, true, st))) return rc;
     rc = match_window_batch(c, 1, (const orb_keypoint*)(d + oK1), d + oD1, (const int*)(d + oN), s1,
                             (const orb_keypoint*)(d + oK2), d + oD2, (const int*)(d + oN) + 1, s2, img_w, img_h,
                             (float*)(d + oPrev), (int*)(d + oM), window, nnratio, check_ori, (int*)(d + oNm), st, true,
                             (int*)(d + oErr));
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(h + oPrev, d + oPrev, L.off - oPrev, hipMemcpyDeviceToHost, st));
+    if ((rc = block_copy(s, oPrev, L.off - oPrev, false, st))) return rc;
     HIP_TRY(hipStreamSynchronize(st));
     if ((rc = match_error((const int*)(h + oErr), s, "windowed matcher", mayRetry))) return rc;
     memcpy(prev_xy, h + oPrev, (size_t)n1 * 8);
@@ -1394,9 +1423,9 @@ static int match_projected_once(orb_ctx* c, int mode, const float* u, const floa
     hipStream_t st = (hipStream_t)orb_ctx_stream(c);
     int* const errw = (int*)(d + oErr);
     B.poolUsed = (unsigned*)errw + 1;
-    HIP_TRY(hipMemcpyAsync(d, h, oM, hipMemcpyHostToDevice, st));
+    if ((rc = block_copy(s, 0, oM, true, st))) return rc;
     const GridGeom G = grid_geom(c, img_w, img_h);
-    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, st, (const orb_keypoint*)(d + oK2), (const int*)nullptr, n2, n2,
+    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(GB_THREADS), 0, st, (const orb_keypoint*)(d + oK2), (const int*)nullptr, n2, n2,
                        G, B, errw, -1);
     if ((rc = check_match_launch())) return rc;
     hipLaunchKernelGGL(k_match_lists<true>, dim3((nq + 3) / 4, 1), dim3(256), 0, st, (const orb_keypoint*)nullptr,
@@ -1414,7 +1443,7 @@ static int match_projected_once(orb_ctx* c, int mode, const float* u, const floa
                        occupied2 ? (const uint8_t*)(d + oOcc) : (const uint8_t*)nullptr, (int*)(d + oM), nnratio, th_high,
                        check_ori, B, (int*)(d + oNm), errw);
     if ((rc = check_match_launch())) return rc;
-    HIP_TRY(hipMemcpyAsync(h + oErr, d + oErr, L.off - oErr, hipMemcpyDeviceToHost, st));
+    if ((rc = block_copy(s, oErr, L.off - oErr, false, st))) return rc;
     HIP_TRY(hipStreamSynchronize(st));
     if ((rc = match_error((const int*)(h + oErr), s, "projected matcher", mayRetry))) return rc;
     memcpy(match2, h + oM, (size_t)n2 * 4);
@@ -1507,9 +1536,9 @@ extern "C" int orb_match_best(orb_ctx* c, const float* u, const float* v, const 
     hipStream_t st = (hipStream_t)orb_ctx_stream(c);
     int* const errw = (int*)(d + oErr);
     B.poolUsed = (unsigned*)errw + 1;
-    HIP_TRY(hipMemcpyAsync(d, h, oIdx, hipMemcpyHostToDevice, st));
+    if ((rc = block_copy(s, 0, oIdx, true, st))) return rc;
     const GridGeom G = grid_geom(c, img_w, img_h);
-    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(256), 0, st, (const orb_keypoint*)(d + oK2), (const int*)nullptr, n2, n2,
+    hipLaunchKernelGGL(k_grid_build, dim3(1), dim3(GB_THREADS), 0, st, (const orb_keypoint*)(d + oK2), (const int*)nullptr, n2, n2,
                        G, B, errw, -1);
     if ((rc = check_match_launch())) return rc;
     hipLaunchKernelGGL(k_match_best, dim3((nq + 3) / 4), dim3(256), 0, st, (const float*)(d + oU), (const float*)(d + oV),
@@ -1517,7 +1546,7 @@ extern "C" int orb_match_best(orb_ctx* c, const float* u, const float* v, const 
                        (const uint8_t*)(d + oD2), ns ? (const float*)(d + oSig) : (const float*)nullptr, ns, chi2_max, th, G,
                        orb_ctx_quirks(c), B, (int*)(d + oIdx), (int*)(d + oDist));
     if ((rc = check_match_launch())) return rc;
-    HIP_TRY(hipMemcpyAsync(h + oErr, d + oErr, L.off - oErr, hipMemcpyDeviceToHost, st));
+    if ((rc = block_copy(s, oErr, L.off - oErr, false, st))) return rc;
     HIP_TRY(hipStreamSynchronize(st));
     if ((rc = match_error((const int*)(h + oErr), s, "orb_match_best", false))) return rc;
     memcpy(best_idx, h + oIdx, (size_t)nq * 4);
