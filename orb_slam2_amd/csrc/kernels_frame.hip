@@ -70,7 +70,10 @@ static UndistortParams make_params(const float K[4], const float dist[5]) {
 }
 
 int orb_ctx_device(const orb_ctx* c);
+void* orb_ctx_stream(orb_ctx* c);
 void orb_ctx_store_bounds(orb_ctx* c, const float* b);
+int orb_stage_block(orb_ctx* c, size_t bytes, void** host, void** dev);                       // kernels_match.hip
+int orb_stage_copy(orb_ctx* c, size_t off, size_t bytes, int toDevice, void* stream);
 
 static int bad_camera(const float* K, const float* dist, const char* who) {
     if (!K || !dist || !(K[0] != 0.f) || !(K[1] != 0.f)) {
@@ -117,24 +120,28 @@ extern "C" int orb_undistort_keypoints(orb_ctx* c, const float K[4], const float
         if (in != out) memcpy(out, in, (size_t)n * sizeof(orb_keypoint));
         return ORB_OK;
     }
+    // through the context's page-locked block and its device copy (no allocation per call), moved by kernels
     hipError_t e = hipSetDevice(orb_ctx_device(c));
-    void *dI = nullptr, *dO = nullptr;
-    if (e == hipSuccess) e = hipMalloc(&dI, (size_t)n * sizeof(orb_keypoint));
-    if (e == hipSuccess) e = hipMalloc(&dO, (size_t)n * sizeof(orb_keypoint));
-    if (e == hipSuccess) e = hipMemcpy(dI, in, (size_t)n * sizeof(orb_keypoint), hipMemcpyHostToDevice);
-    int rc = ORB_OK;
-    if (e == hipSuccess) {
-        rc = orb_undistort_keypoints_device(c, K, dist, (const orb_keypoint*)dI, (orb_keypoint*)dO, n, nullptr);
-        if (rc == ORB_OK) e = hipDeviceSynchronize();
-        if (rc == ORB_OK && e == hipSuccess) e = hipMemcpy(out, dO, (size_t)n * sizeof(orb_keypoint), hipMemcpyDeviceToHost);
-    }
-    if (dI) (void)hipFree(dI);
-    if (dO) (void)hipFree(dO);
     if (e != hipSuccess) {
         orb_set_error("orb_undistort_keypoints: %s", hipGetErrorString(e));
         return ORB_ERR_HIP;
     }
-    return rc;
+    const size_t bytes = ((size_t)n * sizeof(orb_keypoint) + 255) & ~(size_t)255;
+    void *hb = nullptr, *db = nullptr;
+    int rc = orb_stage_block(c, 2 * bytes, &hb, &db);
+    if (rc) return rc;
+    void* const st = orb_ctx_stream(c);
+    memcpy(hb, in, (size_t)n * sizeof(orb_keypoint));
+    if ((rc = orb_stage_copy(c, 0, bytes, 1, st))) return rc;
+    if ((rc = orb_undistort_keypoints_device(c, K, dist, (const orb_keypoint*)db, (orb_keypoint*)((uint8_t*)db + bytes), n, st))) return rc;
+    if ((rc = orb_stage_copy(c, bytes, bytes, 0, st))) return rc;
+    e = hipStreamSynchronize((hipStream_t)st);
+    if (e != hipSuccess) {
+        orb_set_error("orb_undistort_keypoints: %s", hipGetErrorString(e));
+        return ORB_ERR_HIP;
+    }
+    memcpy(out, (const uint8_t*)hb + bytes, (size_t)n * sizeof(orb_keypoint));
+    return ORB_OK;
 }
 
 // Frame::ComputeImageBounds.  Four points: evaluated on the host with the same routine the kernel runs.

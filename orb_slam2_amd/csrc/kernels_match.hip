@@ -1284,6 +1284,28 @@ static int match_error(const int* flag, MatchState* s, const char* what, bool ma
     return ORB_OK;
 }
 
+// The context's transfer block for the other small host-pointer entry points of the library (kernels_frame.hip):
+// *host and *dev receive `bytes` bytes of page-locked memory and their device copy; orb_stage_copy moves
+// [off, off + bytes) one way or the other on the stream (multiples of 16).
+int orb_stage_block(orb_ctx* c, size_t bytes, void** host, void** dev) {
+    MatchState* s = nullptr;
+    MatchBuffers B;
+    int rc = match_buffers(c, 1, 1, 1, &s, &B);  // (creates the state on first use)
+    if (rc) return rc;
+    if ((rc = ensure_block(s, (bytes + 255) & ~(size_t)255))) return rc;
+    *host = s->blockHost;
+    *dev = s->blockDev;
+    return ORB_OK;
+}
+int orb_stage_copy(orb_ctx* c, size_t off, size_t bytes, int toDevice, void* stream) {
+    MatchState* s = (MatchState*)*orb_ctx_match_state(c);
+    if (!s || off + bytes > s->blockBytes || ((off | bytes) & 15)) {
+        orb_set_error("internal: transfer outside the context's block");
+        return ORB_ERR_INVALID;
+    }
+    return block_copy(s, off, bytes, toDevice != 0, (hipStream_t)stream);
+}
+
 // For the asynchronous entry points: called by orb_check_last_batch once the device is idle.
 int orb_match_check_error(orb_ctx* c) {
     MatchState* s = (MatchState*)*orb_ctx_match_state(c);
