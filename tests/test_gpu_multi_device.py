@@ -143,6 +143,44 @@ def test_page_locked_frames_skip_the_staging_copy(oracle):
             x.close()
 
 
+def test_few_host_frames_with_unaligned_rows(oracle):
+    """Calls of fewer than four frames fetch their frames with a kernel that reads the page-locked memory over the
+    link, whole dwords at a time: frames whose rows start at odd addresses, are an odd number of bytes apart and an
+    odd number of pixels wide, page-locked (read where they lie) and pageable (staged first), one to three per
+    call, with other values in the padding.  Results equal the oracle's
+    (unit: ORBextractor::operator(), src/ORBextractor.cc:448-509)."""
+    import ctypes as C
+
+    from orb_slam2_amd import binding
+
+    w, h, stride = 637, 477, 701
+    scenes = [np.ascontiguousarray(synth_scene(640, 480, frame_seed(1, 700 + f))[:h, :w]) for f in range(3)]
+    e = oracle.Extractor(1000, 1.2, 8, 20, 7, 0x1F)
+    c = binding.Context(1000, 1.2, 8, 20, 7, w, h, 4, 0, 0x1F)
+    ref = c.extract_batch(scenes)
+    _same(ref, scenes, e, (0, 1, 2))
+    flat = binding.alloc_host((3 * stride * h + 64,))
+    flat[:] = 0x5C
+    heap = np.full(3 * stride * h + 64, 0xC5, np.uint8)
+    for buf in (flat, heap):
+        views = []
+        for f in range(3):
+            v = np.lib.stride_tricks.as_strided(buf[1 + f * stride * h:], shape=(h, w), strides=(stride, 1))
+            v[:] = scenes[f]
+            views.append(v)
+        for n in (1, 2, 3):
+            kps = np.zeros((n, c.cap), binding.KP_DTYPE)
+            desc = np.zeros((n, c.cap, 32), np.uint8)
+            cnt = np.zeros(n, np.int32)
+            arr = (C.c_void_p * n)(*[views[f].ctypes.data for f in range(n)])
+            rc = binding.lib().orb_extract_batch(c.h, arr, n, w, h, stride, kps.ctypes.data_as(C.c_void_p),
+                                                 desc.ctypes.data_as(C.c_void_p), c.cap, cnt.ctypes.data_as(C.c_void_p))
+            assert rc == 0, binding.lib().orb_last_error()
+            for f in range(n):
+                assert cnt[f] == len(ref[f][0]) and (kps[f, : cnt[f]] == ref[f][0]).all() and (desc[f, : cnt[f]] == ref[f][1]).all()
+    c.close()
+
+
 def test_device_resident_blocks_over_several_contexts(oracle):
     """orb_extract_batch_multi_device: contiguous frame blocks that already lie on their contexts' devices, one
     enqueue per context from the calling thread (own streams and the contexts' streams); a 3840x2160 block
