@@ -173,6 +173,14 @@ int orb_gaussian_blur(orb_ctx* ctx, const uint8_t* src, int w, int h, int sstrid
  * (Examples/Monocular/TUM1.yaml:8-17).  k1 == 0 copies the keypoints, as there. */
 int orb_undistort_keypoints(orb_ctx* ctx, const float K[4], const float dist[5], const orb_keypoint* in,
                             orb_keypoint* out, int n);
+/* ExtractORB and UndistortKeyPoints of the Frame constructor (src/Frame.cc:67-74,
+ * include/Frame.h:121) for one frame in host memory, as one enqueue and one wait
+ * (orb_extract followed by orb_undistort_keypoints costs a second round trip to
+ * the device): kps as orb_extract writes them, kps_un the same keypoints with
+ * undistorted positions (equal to kps when k1 == 0). */
+int orb_extract_undistorted(orb_ctx* ctx, const uint8_t* img, int w, int h, int stride, const float K[4],
+                            const float dist[5], orb_keypoint* kps, orb_keypoint* kps_un, uint8_t* desc, int cap,
+                            int* n_out);
 /* The same on n device-resident keypoints (e.g. a whole batch, n = frames * cap). */
 int orb_undistort_keypoints_device(orb_ctx* ctx, const float K[4], const float dist[5], const orb_keypoint* d_in,
                                    orb_keypoint* d_out, long long n, void* stream);

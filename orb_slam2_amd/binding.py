@@ -35,7 +35,7 @@ EXPORTS = [
     "orb_bf_multi_query_top2", "orb_extract_batch_multi", "orb_extract_batch_multi_device", "orb_alloc_host", "orb_free_host",
     "orb_enable_stage_timing", "orb_get_stage_timings", "orb_last_error", "orb_version",
     "orb_distinctive_descriptors", "orb_distinctive_descriptors_device",
-    "orb_undistort_keypoints", "orb_undistort_keypoints_device", "orb_compute_image_bounds", "orb_set_image_bounds",
+    "orb_undistort_keypoints", "orb_undistort_keypoints_device", "orb_extract_undistorted", "orb_compute_image_bounds", "orb_set_image_bounds",
     "orb_voc_load_text", "orb_voc_create", "orb_voc_destroy", "orb_voc_info", "orb_voc_transform",
     "orb_voc_transform_device", "orb_voc_bow", "orb_bow_score_l1", "orb_match_bow",
     "orb_match_local_map", "orb_match_best", "orb_match_bow_keyframes", "orb_match_triangulation",
@@ -308,6 +308,21 @@ class Context:
         dist = np.ascontiguousarray(dist, np.float32)
         _check(lib().orb_undistort_keypoints(self.h, _p(K), _p(dist), _p(kps), _p(out), len(kps)))
         return out
+
+    def extract_undistorted(self, img, K, dist):
+        """ExtractORB + UndistortKeyPoints of the Frame constructor for one host frame in one call:
+        (keypoints, undistorted keypoints, descriptors)."""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        K = np.ascontiguousarray(K, np.float32)
+        dist = np.ascontiguousarray(dist, np.float32)
+        kps = np.zeros(self.cap, KP_DTYPE)
+        un = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n = C.c_int(0)
+        _check(lib().orb_extract_undistorted(self.h, _p(img), w, h, img.strides[0], _p(K), _p(dist), _p(kps), _p(un), _p(desc),
+                                             self.cap, C.byref(n)))
+        return kps[: n.value], un[: n.value], desc[: n.value]
 
     def undistort_keypoints_device(self, d_in, d_out, n, K, dist, stream=None):
         K = np.ascontiguousarray(K, np.float32)

@@ -44,6 +44,20 @@ void Frame::ComputeBoW() {
     if (mBowVec.empty() && mpORBvocabulary) mpORBvocabulary->transform(mDescriptors, mBowVec, mFeatVec, 4);
 }
 
+// Camera matrix and distortion coefficients in the plain form the C ABI takes.  mDistCoef holds
+// k1, k2, p1, p2 and, when non-zero, k3 (src/Tracking.cc:76-88).
+static bool CameraArrays(const cv::Mat& K, const cv::Mat& D, float k[4], float d[5]) {
+    for (int i = 0; i < 5; i++) d[i] = 0.f;
+    if (K.empty()) return false;
+    k[0] = K.at<float>(0, 0);
+    k[1] = K.at<float>(1, 1);
+    k[2] = K.at<float>(0, 2);
+    k[3] = K.at<float>(1, 2);
+    const int nd = D.empty() ? 0 : std::min(5, D.rows * D.cols);
+    for (int i = 0; i < nd; i++) d[i] = D.at<float>(i);
+    return true;
+}
+
 Frame::Frame(const cv::Mat& imGray, const double& timeStamp, ORBextractor* extractor, ORBVocabulary* voc, cv::Mat& K,
              cv::Mat& distCoef, const float& bf, const float& thDepth)
     : mpORBvocabulary(voc), mpORBextractorLeft(extractor), mpORBextractorRight(static_cast<ORBextractor*>(NULL)),
@@ -61,11 +75,21 @@ Frame::Frame(const cv::Mat& imGray, const double& timeStamp, ORBextractor* extra
     mnImgWidth = imGray.cols;
     mnImgHeight = imGray.rows;
 
-    ExtractORB(0, imGray);
-
-    N = (int)mvKeys.size();
-    if (mvKeys.empty()) return;
-    UndistortKeyPoints();
+    // ExtractORB(0, imGray) and UndistortKeyPoints() (src/Frame.cc:67-74): with a distorted camera both in one call
+    // into the library (one wait for the device instead of two); otherwise as there
+    {
+        float k[4], d[5];
+        if (CameraArrays(mK, mDistCoef, k, d) && d[0] != 0.0f) {
+            mpORBextractorLeft->ExtractUndistorted(imGray, k, d, mvKeys, mvKeysUn, mDescriptors);
+            N = (int)mvKeys.size();
+            if (mvKeys.empty()) return;
+        } else {
+            ExtractORB(0, imGray);
+            N = (int)mvKeys.size();
+            if (mvKeys.empty()) return;
+            UndistortKeyPoints();
+        }
+    }
     mvuRight = std::vector<float>(N, -1);
     mvDepth = std::vector<float>(N, -1);
     mvpMapPoints = std::vector<MapPoint*>(N, static_cast<MapPoint*>(NULL));
@@ -124,20 +148,6 @@ void Frame::UpdatePoseMatrices() {
         for (int k = 0; k < 3; k++) s += mRwc.at<float>(r, k) * mtcw.at<float>(k, 0);
         mOw.at<float>(r, 0) = -s;
     }
-}
-
-// Camera matrix and distortion coefficients in the plain form the C ABI takes.  mDistCoef holds
-// k1, k2, p1, p2 and, when non-zero, k3 (src/Tracking.cc:76-88).
-static bool CameraArrays(const cv::Mat& K, const cv::Mat& D, float k[4], float d[5]) {
-    for (int i = 0; i < 5; i++) d[i] = 0.f;
-    if (K.empty()) return false;
-    k[0] = K.at<float>(0, 0);
-    k[1] = K.at<float>(1, 1);
-    k[2] = K.at<float>(0, 2);
-    k[3] = K.at<float>(1, 2);
-    const int nd = D.empty() ? 0 : std::min(5, D.rows * D.cols);
-    for (int i = 0; i < nd; i++) d[i] = D.at<float>(i);
-    return true;
 }
 
 // Upstream ORB-SLAM2 Frame::UndistortKeyPoints (the fork only declares it, include/Frame.h:121).

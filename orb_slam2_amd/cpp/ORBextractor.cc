@@ -109,6 +109,38 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask*/, s
     if (mbKeepPyramid) DownloadPyramid();
 }
 
+void ORBextractor::ExtractUndistorted(const cv::Mat& image, const float K[4], const float dist[5],
+                                      std::vector<cv::KeyPoint>& keypoints, std::vector<cv::KeyPoint>& keypointsUn,
+                                      cv::Mat& descriptors) {
+    keypoints.clear();
+    keypointsUn.clear();
+    if (image.empty()) return;
+    assert(image.type() == CV_8UC1);
+    EnsureContext(image.cols, image.rows);
+    const int cap = orb_max_keypoints_per_frame(mpCtx);
+    mKpBuf.resize((size_t)cap * sizeof(orb_keypoint));
+    mKpUnBuf.resize((size_t)cap * sizeof(orb_keypoint));
+    mDescBuf.resize((size_t)cap * 32);
+    int n = 0;
+    if (orb_extract_undistorted(mpCtx, image.data, image.cols, image.rows, (int)image.step, K, dist, (orb_keypoint*)mKpBuf.data(),
+                                (orb_keypoint*)mKpUnBuf.data(), mDescBuf.data(), cap, &n))
+        fail("orb_extract_undistorted");
+    keypoints.resize(n);
+    keypointsUn.resize(n);
+    if (n) {
+        memcpy((void*)keypoints.data(), mKpBuf.data(), (size_t)n * sizeof(orb_keypoint));
+        memcpy((void*)keypointsUn.data(), mKpUnBuf.data(), (size_t)n * sizeof(orb_keypoint));
+    }
+    if (n == 0) {
+        descriptors.release();
+    } else {
+        descriptors.create(n, 32, CV_8U);
+        for (int i = 0; i < n; i++) memcpy(descriptors.ptr<unsigned char>(i), mDescBuf.data() + (size_t)i * 32, 32);
+    }
+    mbPyramidCurrent = false;
+    if (mbKeepPyramid) DownloadPyramid();
+}
+
 // src/ORBextractor.cc:913-949: every level is the centre of a buffer EDGE_THRESHOLD = 19 pixels larger on each side,
 // the rim filled by copyMakeBorder(BORDER_REFLECT_101) from the level's own pixels (level 0 likewise: the library sees
 // the caller's image through a pointer and a row stride, never what lies around it).  mvImagePyramid[level] is the

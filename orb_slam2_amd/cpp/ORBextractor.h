@@ -47,6 +47,10 @@ public:
     // ---- additions (no counterpart in the reference) -------------------------------
     void SetKeepPyramid(bool keep) { mbKeepPyramid = keep; }
     const std::vector<cv::Mat>& GetImagePyramid();
+    // operator() and the undistortion of its keypoints (the Frame constructor's ExtractORB + UndistortKeyPoints) as
+    // one call into the library: K = fx, fy, cx, cy; dist = k1, k2, p1, p2, k3.
+    void ExtractUndistorted(const cv::Mat& image, const float K[4], const float dist[5], std::vector<cv::KeyPoint>& keypoints,
+                            std::vector<cv::KeyPoint>& keypointsUn, cv::Mat& descriptors);
     // Behaviour preset and device for extractors constructed afterwards
     // (ORB_QUIRKS_FORK by default; also read from ORBHIP_QUIRKS / ORBHIP_DEVICE).
     static void SetDefaults(unsigned quirks, int device);
@@ -72,7 +76,7 @@ protected:
     void DownloadPyramid();
     unsigned mQuirks;
     int mDevice;
-    std::vector<unsigned char> mKpBuf, mDescBuf;
+    std::vector<unsigned char> mKpBuf, mKpUnBuf, mDescBuf;
     std::vector<std::vector<unsigned char> > mvPaddedLevels;  // the buffers mvImagePyramid's views lie in
 };
 

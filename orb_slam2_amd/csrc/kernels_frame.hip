@@ -57,6 +57,19 @@ __global__ __launch_bounds__(256) void k_undistort(const orb_keypoint* __restric
     out[i] = kp;
 }
 
+// The same over the result block of a frame batch: frame f's first count[f] of `cap` keypoint slots.
+__global__ __launch_bounds__(256) void k_undistort_frames(const orb_keypoint* __restrict__ in, orb_keypoint* __restrict__ out,
+                                                          const int* __restrict__ count, int cap, UndistortParams P) {
+    const int f = blockIdx.y, i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (i >= count[f] || i >= cap) return;
+    orb_keypoint kp = in[(int64_t)f * cap + i];
+    float x, y;
+    undistort_one(P, kp.x, kp.y, &x, &y);
+    kp.x = x;
+    kp.y = y;
+    out[(int64_t)f * cap + i] = kp;
+}
+
 static UndistortParams make_params(const float K[4], const float dist[5]) {
     UndistortParams P;
     P.fx = K[0];
@@ -81,6 +94,22 @@ static int bad_camera(const float* K, const float* dist, const char* who) {
         return 1;
     }
     return 0;
+}
+
+// For orb_extract_undistorted (orb_api.hip): behind the extraction on its stream (dist[0] != 0: the caller copies
+// otherwise, as Frame::UndistortKeyPoints does).
+int orb_launch_undistort_frames(const float K[4], const float dist[5], const orb_keypoint* d_in, orb_keypoint* d_out,
+                                const int* d_count, int cap, int nframes, void* stream) {
+    if (bad_camera(K, dist, "orb_extract_undistorted")) return ORB_ERR_INVALID;
+    const UndistortParams P = make_params(K, dist);
+    hipLaunchKernelGGL(k_undistort_frames, dim3((unsigned)((cap + 255) / 256), (unsigned)nframes), dim3(256), 0, (hipStream_t)stream,
+                       d_in, d_out, d_count, cap, P);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        orb_set_error("orb_extract_undistorted: %s", hipGetErrorString(e));
+        return ORB_ERR_HIP;
+    }
+    return ORB_OK;
 }
 
 extern "C" int orb_undistort_keypoints_device(orb_ctx* c, const float K[4], const float dist[5], const orb_keypoint* d_in,

@@ -202,6 +202,7 @@ struct orb_ctx {
         int ngroups = 1, groupStart[ORB_MAX_PARTS + 1] = {};  // group i > 0 = frames [groupStart[i], groupStart[i + 1]), done at evJoin[i - 1]
         double t0 = 0;               // ORBHIP_HOST_TRACE: when the call began
         size_t offCnt = 0, offKps = 0, offDesc = 0, total = 0;
+        size_t offUn = 0;  // undistorted keypoints in the result block (0: none)
     } hostBatch;
     int lastFrames = 0;
     int lastGroups = 0, lastGroupFrame0[ORB_MAX_PARTS] = {};  // frame groups of the last batch whose quadtree ran in two passes
@@ -1094,8 +1095,10 @@ static bool frames_page_locked(const uint8_t* const* imgs, int n, size_t bytes) 
 // First half of a host-pointer batch: the frames' way to the device, the extraction and the copy of the result block
 // are enqueued on the context's stream; nothing is waited for.  pinnedHint: 1 / 0 when the caller has already
 // looked where the frames live, -1 to find out here.
+int orb_launch_undistort_frames(const float K[4], const float dist[5], const orb_keypoint* d_in, orb_keypoint* d_out,
+                                const int* d_count, int cap, int nframes, void* stream);  // kernels_frame.hip
 static int extract_batch_begin(orb_ctx* c, const uint8_t* const* imgs, int n, int w, int h, int stride, bool wantKps,
-                               bool wantDesc, int pinnedHint) {
+                               bool wantDesc, int pinnedHint, const float* camK = nullptr, const float* camDist = nullptr) {
     if (n < 1 || n > c->prm.max_batch || w > c->prm.max_width || h > c->prm.max_height || stride < w) {
         orb_set_error("orb_extract_batch: batch %d / frame %dx%d stride %d outside the context's limits", n, w, h,
                       stride);
@@ -1252,17 +1255,23 @@ static int extract_batch_begin(orb_ctx* c, const uint8_t* const* imgs, int n, in
     const double T1 = now();
     const size_t offCnt = std::max<size_t>(64, ((size_t)n * 4 + 63) & ~(size_t)63), offKps = offCnt + (((size_t)n * 4 + 63) & ~(size_t)63);
     const size_t offDesc = offKps + (size_t)n * cap * sizeof(orb_keypoint);
-    const size_t total = offDesc + (size_t)n * cap * 32;
+    // (with a camera: the undistorted keypoints behind the descriptors, made by one more kernel on the same stream)
+    const bool undist = camK && camDist && camDist[0] != 0.0f;
+    const size_t offUn = (offDesc + (size_t)n * cap * 32 + 63) & ~(size_t)63;
+    const size_t total = undist ? offUn + (size_t)n * cap * sizeof(orb_keypoint) : offDesc + (size_t)n * cap * 32;
     if ((rc = c->pinOut.ensure(total))) return rc;
     uint8_t* po = (uint8_t*)c->pinOut.p;
     static const bool resultCopy = getenv("ORBHIP_HOST_RESULT_COPY") != nullptr;
-    const bool direct = few || !resultCopy;
+    const bool direct = few || !resultCopy || undist;
     if (direct) {
         uint8_t* dpo = nullptr;  // the block as the device addresses it
         HIP_TRY(hipHostGetDevicePointer((void**)&dpo, po, 0));
         rc = run_batch(c, (const uint8_t*)c->dInput.p, n, w, h, dstride, fstride, (orb_keypoint*)(dpo + offKps), dpo + offDesc,
                        cap, (int*)(dpo + offCnt), c->stream, (int*)dpo, groupIn, parts > 1 ? gs : nullptr, parts);
         if (rc) return rc;
+        if (undist && (rc = orb_launch_undistort_frames(camK, camDist, (const orb_keypoint*)(dpo + offKps), (orb_keypoint*)(dpo + offUn),
+                                                        (const int*)(dpo + offCnt), cap, n, c->stream)))
+            return rc;
     } else {
         if (c->dHostOut.bytes < total) {
             orb_set_error("internal: result block of %zu bytes beyond the context's", total);
@@ -1285,12 +1294,14 @@ static int extract_batch_begin(orb_ctx* c, const uint8_t* const* imgs, int n, in
     c->hostBatch.offKps = offKps;
     c->hostBatch.offDesc = offDesc;
     c->hostBatch.total = total;
+    c->hostBatch.offUn = undist ? offUn : 0;
     if (trace) fprintf(stderr, "host batch %d (%s frames): input enqueued after %.0f us, kernels and result copy after %.0f us\n", n, pinned ? "page-locked" : "pageable", T1 - T0, now() - T0);
     return ORB_OK;
 }
 
 // Second half: waits for the context's stream and unpacks the result block into the caller's arrays.
-static int extract_batch_finish(orb_ctx* c, orb_keypoint* kps, uint8_t* desc, int cap_per_frame, int* n_out) {
+static int extract_batch_finish(orb_ctx* c, orb_keypoint* kps, uint8_t* desc, int cap_per_frame, int* n_out,
+                                orb_keypoint* kpsUn = nullptr) {
     if (!c->hostBatch.open) {
         orb_set_error("orb_extract_batch: no batch to collect");
         return ORB_ERR_INVALID;
@@ -1314,6 +1325,10 @@ static int extract_batch_finish(orb_ctx* c, orb_keypoint* kps, uint8_t* desc, in
                     memcpy(kps + (size_t)f * cap_per_frame, po + offKps + (size_t)f * cap * sizeof(orb_keypoint),
                            (size_t)m * sizeof(orb_keypoint));
                 if (desc) memcpy(desc + (size_t)f * cap_per_frame * 32, po + offDesc + (size_t)f * cap * 32, (size_t)m * 32);
+                if (kpsUn)  // (no distortion: mvKeysUn = mvKeys)
+                    memcpy(kpsUn + (size_t)f * cap_per_frame,
+                           po + (c->hostBatch.offUn ? c->hostBatch.offUn : offKps) + (size_t)f * cap * sizeof(orb_keypoint),
+                           (size_t)m * sizeof(orb_keypoint));
             }
         }
         return ORB_OK;
@@ -1363,6 +1378,28 @@ extern "C" int orb_extract_batch(orb_ctx* c, const uint8_t* const* imgs, int n, 
         return rc;
     }
     return extract_batch_finish(c, kps, desc, cap_per_frame, n_out);
+}
+
+// The extraction of one frame and the undistortion of its keypoints (the Frame constructor's ExtractORB +
+// UndistortKeyPoints, src/Frame.cc:67-74, include/Frame.h:121) as one enqueue and one wait.
+extern "C" int orb_extract_undistorted(orb_ctx* c, const uint8_t* img, int w, int h, int stride, const float K[4],
+                                       const float dist[5], orb_keypoint* kps, orb_keypoint* kps_un, uint8_t* desc, int cap,
+                                       int* n_out) {
+    if (!c || !n_out || !K || !dist || !kps || !kps_un) {
+        orb_set_error("orb_extract_undistorted: null argument");
+        return ORB_ERR_INVALID;
+    }
+    if (!img || w <= 0 || h <= 0) {  // empty image: silent return, src/ORBextractor.cc:451-452
+        *n_out = 0;
+        return ORB_OK;
+    }
+    const uint8_t* one[1] = {img};
+    int rc = extract_batch_begin(c, one, 1, w, h, stride, true, desc != nullptr, -1, K, dist);
+    if (rc) {
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        return rc;
+    }
+    return extract_batch_finish(c, kps, desc, cap, n_out, kps_un);
 }
 
 // Frame blocks over several contexts (one per device), host pointers.  Page-locked frames: the calling thread

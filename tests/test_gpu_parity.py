@@ -794,6 +794,27 @@ def test_undistort_and_image_bounds(hip, oracle):
     c.close()
 
 
+def test_extraction_and_undistortion_in_one_call(hip, oracle):
+    """orb_extract_undistorted = ExtractORB + UndistortKeyPoints of the Frame constructor (src/Frame.cc:67-74,
+    include/Frame.h:121): keypoints and descriptors as orb_extract gives them, undistorted keypoints as the oracle
+    undistorts those; without distortion (k1 == 0) the undistorted keypoints are the keypoints; a frame without
+    keypoints gives none."""
+    c = _ctx(hip, "fork")
+    e = oracle.Extractor(1000, 1.2, 8, 20, 7, PRESETS["fork"])
+    for seed, (w, h) in ((5, (640, 480)), (6, (637, 471))):
+        img = np.ascontiguousarray(synth_scene(640, 480, frame_seed(1, seed))[:h, :w])
+        ko, do = e.extract(img)
+        for D in (TUM1_D, (0, 0, 0, 0, 0), (-0.28, 0.07, 0.0002, 0.00002, 0.0)):
+            k, un, d = c.extract_undistorted(img, TUM1_K, D)
+            assert len(k) == len(ko) and (k == ko).all() and (d == do).all()
+            assert (un == oracle.undistort_keypoints(ko, TUM1_K, D)).all(), "D=%s" % (D,)
+    k, un, d = c.extract_undistorted(np.full((480, 640), 90, np.uint8), TUM1_K, TUM1_D)
+    assert len(k) == 0 and len(un) == 0 and len(d) == 0
+    k2, d2 = c.extract(img)  # the context goes on as before
+    assert (k2 == ko).all() and (d2 == do).all()
+    c.close()
+
+
 @pytest.mark.parametrize("preset", ["fork", "canonical"])
 def test_matchers_with_undistorted_bounds(hip, oracle, preset):
     """Both windowed searches on undistorted keypoints with the grid laid over the undistorted image bounds."""
