@@ -704,6 +704,16 @@ struct ResolveParLds {
     int nmatches, cut;
 };
 
+// Workgroup barrier for code that communicates through LDS only: waits for this wavefront's LDS operations, not for
+// its loads from memory (__syncthreads does: a run's rounds would each wait for the next run's lists, which are
+// fetched meanwhile precisely so that nobody waits for them).
+static __device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (compiler ordering; LDS operations of a wavefront execute in order)
+    __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int MODE>
 __global__ __launch_bounds__(M_PAR_THREADS) void k_match_resolve_par(const orb_keypoint* __restrict__ k1all,
                                                               const int* __restrict__ n1s, int nqConst, int stride1,
@@ -817,6 +827,10 @@ __global__ __launch_bounds__(M_PAR_THREADS) void k_match_resolve_par(const orb_k
     __syncthreads();
 
     int flip = 0;  // which of the two `changed` words the current round uses
+#ifdef MATCH_PROFILE
+    int profRuns = 0, profRounds = 0;
+    const long long profT0 = wall_clock64();
+#endif
     for (int base = 0, buf = 0; base < nActive; base += M_RUN, buf ^= 1) {
         const int a = base + kq;
         const bool in = a < nActive;
@@ -831,7 +845,7 @@ __global__ __launch_bounds__(M_PAR_THREADS) void k_match_resolve_par(const orb_k
         const unsigned long long earlier = kq == 0 ? 0ull : (~0ull >> (64 - kq));
         if (sub == 15) S.k1[kq] = 0xFFFFFFFFu;
         uint32_t mine = 0xFFFFFFFFu;  // this query's claim as posted (best key when accepted)
-        __syncthreads();
+        lds_barrier();
         for (;;) {
             // evaluate against the committed state and the earlier queries' claims of the previous round
             uint32_t a1 = 0xFFFFFFFFu, a2 = 0xFFFFFFFFu;
@@ -877,7 +891,7 @@ __global__ __launch_bounds__(M_PAR_THREADS) void k_match_resolve_par(const orb_k
                 }
                 if (accept) now = a1;
             }
-            __syncthreads();  // every query has read the claims of the previous round
+            lds_barrier();  // every query has read the claims of the previous round
             if (sub == 15 && in && now != mine) {
                 // (projected: a map point without observations takes the keypoint but does not occupy it: no claim)
                 const bool claims = !PROJECTED || obs != 0;
@@ -888,11 +902,17 @@ __global__ __launch_bounds__(M_PAR_THREADS) void k_match_resolve_par(const orb_k
             }
             mine = now;
             if (t == 0) S.changed[flip ^ 1] = 0;
-            __syncthreads();
+            lds_barrier();
             const int again = S.changed[flip];
             flip ^= 1;
+#ifdef MATCH_PROFILE
+            profRounds++;
+#endif
             if (!again) break;
         }
+#ifdef MATCH_PROFILE
+        profRuns++;
+#endif
         // commit the run; take its claims back
         if (sub == 15 && in && mine != 0xFFFFFFFFu) {
             const uint32_t pos = mine & 0xFFFFu;
@@ -907,8 +927,13 @@ __global__ __launch_bounds__(M_PAR_THREADS) void k_match_resolve_par(const orb_k
             S.claims[pos] = 0ull;
         }
         if (base + M_RUN < nActive) stash(buf ^ 1);
-        __syncthreads();
+        lds_barrier();
     }
+#ifdef MATCH_PROFILE
+    if (t == 0 && pair == 0)
+        printf("resolve mode %d: %d queries with candidates, %d runs, %d rounds, %.1f us in the runs\n", MODE, nActive, profRuns, profRounds,
+               (double)(wall_clock64() - profT0) / 100.0);
+#endif
     // Window search: query i1 holds keypoint i2 exactly when i2's owner is i1 at the end, a stolen match having lost
     // its owner (:82-86).  Projected search: the keypoint holds the map point of its last taker.
     __threadfence_block();
