@@ -290,7 +290,11 @@ static __device__ __forceinline__ void qt_one(const OrbGeom* __restrict__ g, con
             return;
         }
         if (q.pass == 1) {  // a node below the bucket depth holds several keys: the second pass takes the level
-            if (t == 0) retry[1 + atomicAdd(&retry[0], 1)] = wg;
+            if (t == 0) {
+                const int k = atomicAdd(&retry[0], 1);
+                if (k < nframes * q.nlevels) retry[3 + k] = wg;  // (always: a (frame, level) lists itself once and the count starts at zero)
+                else atomicOr(error, 4);
+            }
             return;
         }
         __syncthreads();  // ... or, without a second pass (or in it), the sorted form does
@@ -371,12 +375,30 @@ __global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(3, 4))) vo
                levelKeys, retry, error, sh, s_keys, s_region);
         return;
     }
-    // second pass: the levels the first pass listed (its launch is complete: same stream), a few per workgroup
-    const int listed = retry[0];
+    // second pass: the levels the first pass listed (its launch is complete: same stream), a few per workgroup.
+    // retry = count, workgroups of this pass that are done, count of the last launch, entries.  The last workgroup
+    // to finish leaves count and done at zero for the next launch (no clearing launch in between).
+    const int listed = min(retry[0], nframes * q.nlevels);
     for (int i = (int)blockIdx.x; i < listed; i += (int)gridDim.x) {
-        qt_one<(MAXT <= 512 ? 4 : 2)>(g, q, retry[1 + i], frame0, nframes, cellKeys, cellCount, codeTab, sortBuf, nodes, ints, selXY, selScore, levelCount,
+        qt_one<(MAXT <= 512 ? 4 : 2)>(g, q, retry[3 + i], frame0, nframes, cellKeys, cellCount, codeTab, sortBuf, nodes, ints, selXY, selScore, levelCount,
                levelKeys, retry, error, sh, s_keys, s_region);
         __syncthreads();
+    }
+    // Only the workgroups that had levels to take count themselves done (hundreds of atomics on one word cost more
+    // than the clearing launch they replace); the others found nothing to do whether they read the count before or
+    // after it was cleared.
+    const int takers = min(listed, (int)gridDim.x);
+    if ((int)blockIdx.x >= takers) {
+        if (listed == 0 && blockIdx.x == 0 && threadIdx.x == 0) retry[2] = 0;
+        return;
+    }
+    if (threadIdx.x == 0) {  // (behind the loop's last barrier: every wavefront of the workgroup has read the count)
+        __threadfence();
+        if (atomicAdd(&retry[1], 1) == takers - 1) {
+            retry[2] = listed;
+            retry[0] = 0;
+            retry[1] = 0;
+        }
     }
 }
 
@@ -448,13 +470,6 @@ static int qt_launch(const OrbBatch& b, bool bigFrames, int pass) {
     // every frame group of a batch has its own list (a count, then at most one entry per (frame, level))
     int* retry = b.d_qtRetry + (int64_t)b.frame0 * (g.nlevels + 1);
     const int all = b.nframes * q.nlevels;
-    if (pass == 1) {
-        hipError_t em = hipMemsetAsync(retry, 0, sizeof(int), (hipStream_t)b.stream);
-        if (em != hipSuccess) {
-            orb_set_error("quadtree: %s", hipGetErrorString(em));
-            return ORB_ERR_HIP;
-        }
-    }
     hipLaunchKernelGGL(bigFrames ? k_quadtree<QT_MAX_THREADS> : k_quadtree<512>, dim3(pass == 2 ? std::min(all, 1024) : all), dim3(threads), lds, (hipStream_t)b.stream, b.d_geom, q,
                        b.frame0, b.nframes, b.d_cellKeys, b.d_cellCount, b.d_codeTab, b.d_sort, b.d_nodes, b.d_ints, b.d_selXY, b.d_selScore, b.d_levelCount,
                        b.d_levelKeys, retry, b.d_error);
@@ -470,7 +485,8 @@ static int qt_launch(const OrbBatch& b, bool bigFrames, int pass) {
 // once anyway) by the latency of one workgroup: two passes when the first one's smaller histograms make a
 // difference to the former.
 bool orb_quadtree_two_passes(const OrbGeom& g, int nframes) {
-    if (g.lv[0].keyCap > ORB_QT_BIG_KEYCAP || !qt_large_launch(nframes * g.nlevels)) return false;
+    // (three frames at least: a frame group's list has room for three words in front of its nframes x nlevels entries)
+    if (g.lv[0].keyCap > ORB_QT_BIG_KEYCAP || !qt_large_launch(nframes * g.nlevels) || nframes < 3) return false;
     for (int l = 0; l < g.nlevels; l++)
         if (g.lv[l].histDepthFirst < g.lv[l].histDepth) return true;
     return false;

@@ -700,7 +700,13 @@ static int ensure_buffers(orb_ctx* c, int n) {
     if ((rc = c->dSelScore.ensure((size_t)n * g.outCapFrame * 4))) return rc;
     if ((rc = c->dLevelCount.ensure((size_t)n * g.nlevels * 4))) return rc;
     if ((rc = c->dLevelKeys.ensure((size_t)n * g.nlevels * 4))) return rc;
-    if ((rc = c->dQtRetry.ensure(((size_t)n * (g.nlevels + 1) + 1) * 4))) return rc;
+    {   // the quadtree's second-pass lists: three words (count, workgroups done, last count) and the entries per frame
+        // group; the kernels leave count and done at zero, so the words only need clearing when the block is made
+        const size_t need = ((size_t)n * (g.nlevels + 1) + 4) * 4;
+        const void* before = c->dQtRetry.p;
+        if ((rc = c->dQtRetry.ensure(need))) return rc;
+        if (c->dQtRetry.p != before) HIP_TRY(hipMemset(c->dQtRetry.p, 0, c->dQtRetry.bytes));
+    }
     if (!c->dHostOut.p) {
         const size_t frames = (size_t)std::max(n, c->prm.max_batch), cap = (size_t)orb_max_keypoints_per_frame(c);
         if ((rc = c->dHostOut.ensure(64 + 2 * ((frames * 4 + 63) & ~(size_t)63) + frames * cap * (sizeof(orb_keypoint) + 32)))) return rc;
@@ -1042,8 +1048,8 @@ extern "C" int orb_quadtree_second_pass_levels(orb_ctx* c, int* levels) {
     int total = 0;
     for (int i = 0; i < c->lastGroups; i++) {
         int n = 0;
-        HIP_TRY(hipMemcpy(&n, (const int*)c->dQtRetry.p + (int64_t)c->lastGroupFrame0[i] * (c->geom.nlevels + 1), sizeof(int),
-                          hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&n, (const int*)c->dQtRetry.p + (int64_t)c->lastGroupFrame0[i] * (c->geom.nlevels + 1) + 2, sizeof(int),
+                          hipMemcpyDeviceToHost));  // (the count of the last launch, kept by the second pass)
         total += n;
     }
     *levels = total;

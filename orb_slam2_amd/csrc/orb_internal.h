@@ -207,7 +207,7 @@ struct OrbBatch {  // everything one extraction launch sequence needs
     int* d_selScore;            // [frame][outCapFrame]
     int* d_levelCount;          // [frame][nlevels] keypoints kept per level
     int* d_levelKeys;           // [frame][nlevels] keys handed to the quadtree (counted by the FAST kernel)
-    int* d_qtRetry;             // quadtree levels handed to the second pass: per frame group a count, then workgroup numbers
+    int* d_qtRetry;             // quadtree levels handed to the second pass: per frame group count, workgroups done, last count, then workgroup numbers
     int* d_error;               // flag word, OR of limit bits
     int* d_status;              // optional: per frame, the flag word as the last stage saw it (may be host memory)
     orb_keypoint* d_kps;

@@ -114,5 +114,18 @@ def test_quadtree_second_pass_takes_the_crowded_levels(oracle, quirks, monkeypat
     for f in (0, 3, 7):
         ko, do = ext.extract(frames[f])
         assert len(ko) == len(res[f][0]) and (ko == res[f][0]).all() and (do == res[f][1]).all(), f
+    # the second pass leaves its lists empty for the next batch: ordinary frames next (fewer levels listed, if any),
+    # then the first batch again, with the frames in another order (other frame groups hold the crowded ones)
+    plain = [_frame(w, h, 700 + i) for i in range(12)]
+    res2 = ctx.extract_batch(plain)
+    assert ctx.quadtree_second_pass_levels() < second
+    for f in (0, 5, 11):
+        k, d = one.extract(plain[f])
+        assert np.array_equal(k, res2[f][0]) and np.array_equal(d, res2[f][1]), f
+    order = [11, 0, 7, 3, 9, 1, 6, 2, 10, 4, 8, 5]
+    res3 = ctx.extract_batch([frames[f] for f in order])
+    assert ctx.quadtree_second_pass_levels() == second
+    for k_, f in enumerate(order):
+        assert np.array_equal(res3[k_][0], res[f][0]) and np.array_equal(res3[k_][1], res[f][1]), f
     ctx.close()
     one.close()
