@@ -124,6 +124,7 @@ __global__ __launch_bounds__(GB_THREADS) void k_grid_build(const orb_keypoint* _
     const orb_keypoint* k2 = k2all + (int64_t)pair * stride2;
     int* cellStart = B.cellStart + (int64_t)pair * (M_CELLS + 1);
     const int n2 = n2s ? n2s[pair] : n2const;
+    if (pair == 0 && t == 0) *B.poolUsed = 0u;  // the call's pool counter starts at zero (the list kernel, next on the stream, counts)
     if (n2 > stride2 || n2 > M_MAXKP || n2 < 0) {
         if (t == 0) atomicOr(error, M_ERR_LIMIT);
         for (int c = t; c <= M_CELLS; c += GB_THREADS) cellStart[c] = 0;  // an empty grid: the later kernels find nothing
@@ -1201,7 +1202,6 @@ static int match_window_batch(orb_ctx* c, int npairs, const orb_keypoint* d_k1, 
     hipLaunchKernelGGL(k_grid_build, dim3(npairs), dim3(GB_THREADS), 0, st, d_k2, d_n2, 0, stride2, G, B,
                        errw, 0);
     if ((rc = check_match_launch())) return rc;
-    if (!blockErr) HIP_TRY(hipMemsetAsync(B.poolUsed, 0, 4, st));
     hipLaunchKernelGGL(k_match_lists<false>, dim3((stride1 + 3) / 4, npairs), dim3(256), 0, st, d_k1, d_d1, d_n1, 0,
                        stride1, (const float*)d_prev_xy, (float)window, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const int*)nullptr, (const int*)nullptr, d_d2, stride2, G, orb_ctx_quirks(c), B,
