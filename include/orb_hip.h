@@ -14,7 +14,9 @@
  * Pointers named d_* are device pointers on the context's device, all others
  * are host pointers.  `stream` is a hipStream_t passed as void* (NULL = the
  * null stream).  The *_device entry points enqueue work and return without
- * synchronising.
+ * synchronising.  The host-pointer entry points work on a stream of the
+ * context's own (non-blocking: it does not wait for the null stream) and
+ * return when their results are in the caller's arrays.
  */
 #ifndef ORB_HIP_H
 #define ORB_HIP_H
