@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <cstring>
 
 #include "orb_internal.h"
 
@@ -103,6 +104,9 @@ int orb_launch_distinctive(const uint8_t* d_desc, const int* d_offsets, int npoi
 }
 
 int orb_ctx_device(const orb_ctx* c);
+void* orb_ctx_stream(orb_ctx* c);
+int orb_stage_block(orb_ctx* c, size_t bytes, void** host, void** dev);                       // kernels_match.hip
+int orb_stage_copy(orb_ctx* c, size_t off, size_t bytes, int toDevice, void* stream);
 
 extern "C" int orb_distinctive_descriptors_device(orb_ctx* c, const uint8_t* d_desc, const int* d_offsets, int npoints,
                                                   int self_distance, int* d_best_index, int* d_best_median,
@@ -146,28 +150,32 @@ extern "C" int orb_distinctive_descriptors(orb_ctx* c, const uint8_t* desc, cons
         orb_set_error("orb_distinctive_descriptors: null descriptor array");
         return ORB_ERR_INVALID;
     }
+    // through the context's page-locked block and its device copy (no allocation per call), on the context's stream
     hipError_t e = hipSetDevice(orb_ctx_device(c));
-    void *dD = nullptr, *dO = nullptr, *dB = nullptr, *dM = nullptr;
-    if (e == hipSuccess) e = hipMalloc(&dD, (size_t)(total > 0 ? total : 1) * 32);
-    if (e == hipSuccess) e = hipMalloc(&dO, (size_t)(npoints + 1) * 4);
-    if (e == hipSuccess) e = hipMalloc(&dB, (size_t)npoints * 4);
-    if (e == hipSuccess) e = hipMalloc(&dM, (size_t)npoints * 4);
-    if (e == hipSuccess && total > 0) e = hipMemcpy(dD, desc, (size_t)total * 32, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(dO, offsets, (size_t)(npoints + 1) * 4, hipMemcpyHostToDevice);
-    int rc = ORB_OK;
-    if (e == hipSuccess) {
-        rc = orb_launch_distinctive((const uint8_t*)dD, (const int*)dO, npoints, self_distance, (int*)dB, (int*)dM, nullptr);
-        if (rc == ORB_OK) e = hipDeviceSynchronize();
-        if (rc == ORB_OK && e == hipSuccess) e = hipMemcpy(best_index, dB, (size_t)npoints * 4, hipMemcpyDeviceToHost);
-        if (rc == ORB_OK && e == hipSuccess && best_median)
-            e = hipMemcpy(best_median, dM, (size_t)npoints * 4, hipMemcpyDeviceToHost);
-    }
-    void* bufs[] = {dD, dO, dB, dM};
-    for (void* b : bufs)
-        if (b) (void)hipFree(b);
     if (e != hipSuccess) {
         orb_set_error("orb_distinctive_descriptors: %s", hipGetErrorString(e));
         return ORB_ERR_HIP;
     }
-    return rc;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t oD = 0, oO = oD + up((size_t)total * 32), oB = oO + up((size_t)(npoints + 1) * 4), oM = oB + up((size_t)npoints * 4);
+    const size_t end = oM + up((size_t)npoints * 4);
+    void *hb = nullptr, *db = nullptr;
+    int rc = orb_stage_block(c, end, &hb, &db);
+    if (rc) return rc;
+    uint8_t* const h = (uint8_t*)hb;
+    uint8_t* const d = (uint8_t*)db;
+    void* const st = orb_ctx_stream(c);
+    if (total > 0) memcpy(h + oD, desc, (size_t)total * 32);
+    memcpy(h + oO, offsets, (size_t)(npoints + 1) * 4);
+    if ((rc = orb_stage_copy(c, 0, oB, 1, st))) return rc;
+    if ((rc = orb_launch_distinctive(d + oD, (const int*)(d + oO), npoints, self_distance, (int*)(d + oB), (int*)(d + oM), st))) return rc;
+    if ((rc = orb_stage_copy(c, oB, end - oB, 0, st))) return rc;
+    e = hipStreamSynchronize((hipStream_t)st);
+    if (e != hipSuccess) {
+        orb_set_error("orb_distinctive_descriptors: %s", hipGetErrorString(e));
+        return ORB_ERR_HIP;
+    }
+    memcpy(best_index, h + oB, (size_t)npoints * 4);
+    if (best_median) memcpy(best_median, h + oM, (size_t)npoints * 4);
+    return ORB_OK;
 }
