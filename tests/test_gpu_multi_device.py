@@ -35,7 +35,7 @@ def test_multi_device_brute_force_equals_oracle(oracle):
         m = binding.MultiBruteForce(devs)
         assert m.exchange == ("rccl" if len(set(devs)) == len(devs) else "copy")
         m.set_database(db)
-        for nq in (1300, 77):  # second call with fewer queries on the same buffers
+        for nq in (100, 1300, 77, 900):  # the buffers grow (100 -> 1300), then serve fewer queries as they are
             ig, bg, sg = m.query_top2(q[:nq])
             np.testing.assert_array_equal(ig, io[:nq], err_msg="devices %s" % devs)
             np.testing.assert_array_equal(bg, bo[:nq])
