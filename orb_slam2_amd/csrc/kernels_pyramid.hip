@@ -8,6 +8,7 @@
 // is 8.8 fixed point.  Results therefore do not depend on the tiling.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "orb_internal.h"
@@ -33,6 +34,7 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;
 #define RS_TILES_PER_WG_MANY 4
 #define RS_MANY_FRAMES 256
 #define RS_STAGE_REGS 6  // dwords of a source tile one thread can hold while the previous tile is worked on
+#define RS_WAVE_TH 8     // tile height of the one-wavefront shape
 
 // Everything about one workgroup's column of tiles that does not change from tile to tile.
 struct RsTileCtx {
@@ -44,7 +46,7 @@ struct RsTileCtx {
 };
 
 // Horizontal pass: column dx of every staged row.
-template <bool AREA, int NT>
+template <bool AREA, int NT, int NW>
 static __device__ __forceinline__ void rs_horizontal(const RsTileCtx& c, const OrbAreaTap& txa, const OrbLinTap& txl,
                                                      int nrows) {
     if (!c.colValid) return;
@@ -61,9 +63,9 @@ static __device__ __forceinline__ void rs_horizontal(const RsTileCtx& c, const O
         // the row pitch it forms both addresses anew in every step.
         unsigned a0 = (unsigned)(uintptr_t)(lds_u8*)c.tile + 4u * (unsigned)((b0 >> 2) + 2 * c.q * rowStep);
         unsigned a1 = a0 + 4u * (unsigned)rowStep;
-        const unsigned aStep = 32u * (unsigned)rowStep;
+        const unsigned aStep = 8u * NW * (unsigned)rowStep;
         float* out = c.bufF + 2 * c.q * ORB_RS_TW + c.dx;
-        for (int r = 2 * c.q; r < nrows; r += 8, a0 += aStep, a1 += aStep, out += 8 * ORB_RS_TW) {
+        for (int r = 2 * c.q; r < nrows; r += 2 * NW, a0 += aStep, a1 += aStep, out += 2 * NW * ORB_RS_TW) {
             const lds_u32* p0 = (const lds_u32*)(uintptr_t)a0;
             const lds_u32* p1 = (const lds_u32*)(uintptr_t)a1;
             const uint32_t w0 = __builtin_amdgcn_alignbyte(p0[1], p0[0], sh);
@@ -84,7 +86,7 @@ static __device__ __forceinline__ void rs_horizontal(const RsTileCtx& c, const O
         }
     } else {
         int* bufI = (int*)c.bufF;
-        for (int r = c.q; r < nrows; r += 4) {
+        for (int r = c.q; r < nrows; r += NW) {
             const uint8_t* rowp = c.tile + r * c.tp - c.sxa;  // rowp[sx] is source pixel (sx, sy0 + r)
             bufI[r * ORB_RS_TW + c.dx] = rowp[txl.s0] * txl.a0 + rowp[txl.s1] * txl.a1;
         }
@@ -93,7 +95,7 @@ static __device__ __forceinline__ void rs_horizontal(const RsTileCtx& c, const O
 
 // Vertical pass: four adjacent columns of one destination row per thread and round; the tile's vertical taps
 // are in LDS at `taps`.
-template <bool AREA, int NT>
+template <bool AREA, int NT, int NW, int TH>
 static __device__ __forceinline__ void rs_vertical(const RsTileCtx& c, const void* taps, int t, int x0, int y0, int sy0,
                                                    uint8_t* __restrict__ dstFrame, int dw, int dh, int dpitch) {
     const int cg = t & 15;
@@ -102,7 +104,7 @@ static __device__ __forceinline__ void rs_vertical(const RsTileCtx& c, const voi
     const bool dwordRows = ((((unsigned long long)dstFrame) | (unsigned long long)(unsigned)dpitch) & 3ull) == 0;  // uniform
     const int* bufI = (const int*)c.bufF;
 #pragma unroll
-    for (int row = t >> 4; row < ORB_RS_TH; row += 16) {
+    for (int row = t >> 4; row < TH; row += 4 * NW) {
         const int y = y0 + row;
         if (y >= dh) break;
         uint32_t outw = 0u;
@@ -148,20 +150,26 @@ static __device__ __forceinline__ void rs_vertical(const RsTileCtx& c, const voi
 }
 
 // NT = taps per axis the area tables use at most (3 for any level ratio below 2, else ORB_MAX_TAPS).
-// PAIR: the workgroup makes two vertically adjacent tiles and fetches the source rows of the second into
-// registers while it works on the first (a wavefront otherwise spends most of its life waiting for its
+// PAIR: the workgroup makes several vertically adjacent tiles and fetches the source rows of the next into
+// registers while it works on the current one (a wavefront otherwise spends most of its life waiting for its
 // tile); needs a tile to be at most RS_STAGE_REGS dwords per thread, which the launcher checks.
-template <bool AREA, int NT, bool PAIR>
-__global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict__ src, int sw, int sh, int sstride,
+// NW wavefronts make tiles of ORB_RS_TW x TH pixels.  Two shapes are launched: four wavefronts on 64 x 32 tiles,
+// and one wavefront on 64 x 8 tiles (EXACT: the staged source span is read off the tap tables -- first tap of the
+// tile's first index to last tap of its last -- instead of the wider span orb_resize_span bounds it with; a
+// one-wavefront workgroup waits for nobody at its barriers, and its LDS is free again the moment it ends).
+template <bool AREA, int NT, bool PAIR, int NW, int TH, bool EXACT>
+__global__ __launch_bounds__(64 * NW) void k_resize_tiled(const uint8_t* __restrict__ src, int sw, int sh, int sstride,
                                                       int64_t sFrame, uint8_t* __restrict__ dst, int dw, int dh,
                                                       int dpitch, int64_t dFrame, const void* __restrict__ xtab,
                                                       const void* __restrict__ ytab, uint64_t scaleX, uint64_t scaleY,
                                                       int tp, int rowsMax, int tilesX, int tilesY, int nframes,
                                                       unsigned tilesXMagic, unsigned tilesMagic, int srcPadded, int tilesPerWg) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_mem[];
+    constexpr int NTHREADS = 64 * NW;
+    constexpr int RPP = 2 * NW;  // rows per staging pass of the uniform-row mapping (32 dword columns per row)
     const int t = threadIdx.x;
     RsTileCtx c;
-    c.tile = s_mem + ORB_RS_TAP_BYTES;
+    c.tile = s_mem + TH * 32;
     c.bufF = (float*)(c.tile + (((size_t)tp * rowsMax + 15) & ~(size_t)15));  // [rowsMax][ORB_RS_TW]
     c.tp = tp;
     c.dx = t & 63;
@@ -180,14 +188,24 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
         else txl = ((const OrbLinTap*)xtab)[x0 + c.dx];
     }
     int sx0, sx1;
-    orb_resize_span(x0, x1, scaleX, sw, &sx0, &sx1);
+    if (EXACT) {  // (uniform addresses: scalar loads)
+        if (AREA) {
+            sx0 = ((const OrbAreaTap*)xtab)[x0].si[0];
+            sx1 = ((const OrbAreaTap*)xtab)[x1 - 1].si[ORB_MAX_TAPS - 1];
+        } else {
+            sx0 = ((const OrbLinTap*)xtab)[x0].s0;
+            sx1 = ((const OrbLinTap*)xtab)[x1 - 1].s1;
+        }
+    } else {
+        orb_resize_span(x0, x1, scaleX, sw, &sx0, &sx1);
+    }
     c.sxa = sx0 & ~3;
     const int nd = (sx1 - c.sxa + 4) >> 2;
     const uint8_t* S = src + (int64_t)frameLocal * sFrame;
     uint8_t* D = dst + (int64_t)frameLocal * dFrame;
     const bool aligned = (sstride & 3) == 0 && (((unsigned long long)S) & 3ull) == 0;
-    // staging: thread = (row within a pass, dword); a pass covers 256 / nd rows (nd <= 256: checked by the launcher)
-    const int rpp = orb_div_small(256, nd);
+    // staging: thread = (row within a pass, dword); a pass covers NTHREADS / nd rows (nd <= NTHREADS: checked by the launcher)
+    const int rpp = orb_div_small(NTHREADS, nd);
     const int rr = orb_div_small(t, nd), d = t - rr * nd;
     const int col = c.sxa + 4 * d;
     const bool stager = rr < rpp;
@@ -207,7 +225,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
     };
     // the tile's vertical taps; the area taps' source rows as byte offsets into the horizontal results of this tile
     auto stage_taps = [&](int y0, int sy0) {
-        if (t < ORB_RS_TH && y0 + t < dh) {
+        if (t < TH && y0 + t < dh) {
             if (AREA) {
                 OrbAreaTap ty = ((const OrbAreaTap*)ytab)[y0 + t];
 #pragma unroll
@@ -220,27 +238,49 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
     };
     auto rows_of = [&](int y0, int* sy0, int* nrows) {
         int s0, s1;
-        orb_resize_span(y0, min(y0 + ORB_RS_TH, dh), scaleY, sh, &s0, &s1);
+        const int y1 = min(y0 + TH, dh);
+        if (EXACT) {
+            if (AREA) {
+                s0 = ((const OrbAreaTap*)ytab)[y0].si[0];
+                s1 = ((const OrbAreaTap*)ytab)[y1 - 1].si[ORB_MAX_TAPS - 1];
+            } else {
+                s0 = ((const OrbLinTap*)ytab)[y0].s0;
+                s1 = ((const OrbLinTap*)ytab)[y1 - 1].s1;
+            }
+        } else {
+            orb_resize_span(y0, y1, scaleY, sh, &s0, &s1);
+        }
         *sy0 = s0;
         *nrows = s1 - s0 + 1;
     };
+    // (a one-wavefront workgroup needs no hardware barrier: its LDS operations execute in order)
+    auto wg_sync = [&]() {
+        if (NW == 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
+    };
 
     if (!PAIR) {
-        const int y0 = by * ORB_RS_TH;
+        const int y0 = by * TH;
         int sy0, nrows;
         rows_of(y0, &sy0, &nrows);
         stage_taps(y0, sy0);
         if (stager)
             for (int r = rr; r < nrows; r += rpp) *(uint32_t*)&c.tile[r * tp + 4 * d] = fetch(sy0, r);
-        __syncthreads();
-        rs_horizontal<AREA, NT>(c, txa, txl, nrows);
-        __syncthreads();
-        rs_vertical<AREA, NT>(c, s_mem, t, x0, y0, sy0, D, dw, dh, dpitch);
+        wg_sync();
+        rs_horizontal<AREA, NT, NW>(c, txa, txl, nrows);
+        wg_sync();
+        rs_vertical<AREA, NT, NW, TH>(c, s_mem, t, x0, y0, sy0, D, dw, dh, dpitch);
         return;
     }
 
     // Staging of a tile, PAIR instances.  On 4-byte-aligned sources whose tile rows are at most 32 dwords a thread
-    // is (row within a pass of eight, dword) and a pass starts at row min(8 k, nrows - 8): the row numbers are the
+    // is (row within a pass of RPP, dword) and a pass starts at row min(RPP k, nrows - RPP): the row numbers are the
     // same for all lanes of a wavefront, so a row's address is scalar arithmetic plus the thread's constant part --
     // one vector instruction per load and per store, no branches; the last passes fetch and store rows the earlier
     // ones already did (same bytes to the same place) instead of being cut short.  Threads whose dword straddles
@@ -261,7 +301,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
                     const unsigned lo = __umul24((unsigned)min(rl, fn - 1), (unsigned)sstride) + (unsigned)colU;
 #pragma unroll
                     for (int k = 0; k < RS_STAGE_REGS; k++) {
-                        const unsigned r0 = (unsigned)max(0, min(8 * k, fn - 8));
+                        const unsigned r0 = (unsigned)max(0, min(RPP * k, fn - RPP));
                         held[k] = *(const uint32_t*)(S + (((unsigned)fy0 + r0) * (unsigned)sstride + lo));
                     }
                 }
@@ -284,13 +324,13 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
                 if (dwordOkU) {
 #pragma unroll
                     for (int k = 0; k < RS_STAGE_REGS; k++) {
-                        unsigned ro = (unsigned)max(0, min(8 * k, fn - 8)) * (unsigned)tp;
+                        unsigned ro = (unsigned)max(0, min(RPP * k, fn - RPP)) * (unsigned)tp;
                         asm volatile("" : "+s"(ro));
                         *(lds_u32*)(uintptr_t)(ldsLane + ro) = held[k];
                     }
                 } else {  // a dword that straddles the image width: fetched now, byte by byte
                     for (int k = 0; k < RS_STAGE_REGS; k++) {
-                        const int r0 = max(0, min(8 * k, fn - 8));
+                        const int r0 = max(0, min(RPP * k, fn - RPP));
                         const uint8_t* p = S + (((unsigned)(fy0 + r0 + rlc)) * (unsigned)sstride + (unsigned)colU);
                         uint32_t v = 0u;
                         for (int i = 0; i < 4; i++)
@@ -307,7 +347,7 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
             }
         };
 
-        int y0 = by * (tilesPerWg * ORB_RS_TH);
+        int y0 = by * (tilesPerWg * TH);
         int sy0, nrows;
         rows_of(y0, &sy0, &nrows);
         uint32_t held[RS_STAGE_REGS];
@@ -315,20 +355,20 @@ __global__ __launch_bounds__(256) void k_resize_tiled(const uint8_t* __restrict_
         for (int s = 0; s < tilesPerWg; s++) {
             store_tile(sy0, nrows, held);
             stage_taps(y0, sy0);
-            __syncthreads();
-            // the second tile's rows are requested now and awaited after the first tile is done
-            const int ny0 = y0 + ORB_RS_TH;
+            wg_sync();
+            // the next tile's rows are requested now and awaited after this tile is done
+            const int ny0 = y0 + TH;
             const bool more = s + 1 < tilesPerWg && ny0 < dh;
             int nsy0 = 0, nnrows = 0;
             if (more) {
                 rows_of(ny0, &nsy0, &nnrows);
                 fetch_tile(nsy0, nnrows, held);
             }
-            rs_horizontal<AREA, NT>(c, txa, txl, nrows);
-            __syncthreads();
-            rs_vertical<AREA, NT>(c, s_mem, t, x0, y0, sy0, D, dw, dh, dpitch);
+            rs_horizontal<AREA, NT, NW>(c, txa, txl, nrows);
+            wg_sync();
+            rs_vertical<AREA, NT, NW, TH>(c, s_mem, t, x0, y0, sy0, D, dw, dh, dpitch);
             if (!more) break;
-            __syncthreads();  // tile, horizontal results and taps are free again
+            wg_sync();  // tile, horizontal results and taps are free again
             y0 = ny0;
             sy0 = nsy0;
             nrows = nnrows;
@@ -417,9 +457,11 @@ static int check_launch(const char* what) {
     return ORB_OK;
 }
 
+// exactTp / exactRows8: LDS row pitch and source rows of the largest 64 x 8 tile when its span is read off the tap
+// tables (OrbLevel::rsTpExact / rsRows8; 0 = not known, as for a stand-alone resize).
 static int launch_resize(bool area, int ntaps, const uint8_t* src, int sw, int sh, int sstride, int64_t sFrame, uint8_t* dst, int dw,
                          int dh, int dpitch, int64_t dFrame, const void* xt, const void* yt, int nframes,
-                         hipStream_t st, bool srcPadded) {
+                         hipStream_t st, bool srcPadded, int exactTp = 0, int exactRows8 = 0) {
     if ((int64_t)sh * sstride > 0x7fffffffll || sh >= (1 << 24) || sstride >= (1 << 24)) {
         orb_set_error("resize: a source frame of %d rows of %d bytes is beyond the kernel's 32-bit row offsets", sh, sstride);
         return ORB_ERR_UNSUPPORTED;
@@ -429,6 +471,33 @@ static int launch_resize(bool area, int ntaps, const uint8_t* src, int sw, int s
         return ORB_ERR_UNSUPPORTED;
     }
     const uint64_t scaleX = orb_resize_scale_fx(sw, dw), scaleY = orb_resize_scale_fx(sh, dh);
+    const int tilesX = (dw + ORB_RS_TW - 1) / ORB_RS_TW;
+    // One wavefront per workgroup on 64 x 8 tiles: sources in 4-byte-aligned rows whose tiles are at most 32 dwords
+    // wide and 2 * RS_STAGE_REGS rows high (any level ratio up to about 1.3); ORBHIP_RS_WAVE=0 keeps the four-wavefront shape.
+    static const int waveMode = getenv("ORBHIP_RS_WAVE") ? atoi(getenv("ORBHIP_RS_WAVE")) : 1;
+    static const int waveTiles = getenv("ORBHIP_RS_WAVE_TILES") ? atoi(getenv("ORBHIP_RS_WAVE_TILES")) : 0;
+    const int tilesY8 = (dh + RS_WAVE_TH - 1) / RS_WAVE_TH;
+    if (waveMode && exactTp > 0 && exactRows8 > 0 && exactTp / 4 <= 32 && exactRows8 <= 2 * RS_STAGE_REGS && tilesY8 > 1 &&
+        ((((unsigned long long)src) | (unsigned long long)sstride | (unsigned long long)sFrame) & 3ull) == 0) {
+        const int rowsW = exactRows8 + 1;  // the horizontal pass works on pairs of rows
+        const size_t ldsW = RS_WAVE_TH * 32 + (((size_t)exactTp * rowsW + 15) & ~(size_t)15) + (size_t)rowsW * ORB_RS_TW * 4;
+        // tiles per wavefront: as many as leave the launch about three wavefronts per slot of the chip, 2 .. 8
+        const int64_t tilesAll = (int64_t)tilesX * tilesY8 * nframes;
+        int tpw = waveTiles > 0 ? waveTiles : (int)std::max<int64_t>(2, std::min<int64_t>(8, tilesAll / (3 * 8192)));
+        tpw = std::min(tpw, tilesY8);
+        const int tilesYwgW = (tilesY8 + tpw - 1) / tpw;
+        const dim3 gridW((unsigned)orb_xcd_grid(nframes, (int64_t)tilesX * tilesYwgW));
+#define RS_LAUNCH_WAVE(AREA_, NT_)                                                                                          \
+    hipLaunchKernelGGL((k_resize_tiled<AREA_, NT_, true, 1, RS_WAVE_TH, true>), gridW, dim3(64), ldsW, st, src, sw, sh, sstride, \
+                       sFrame, dst, dw, dh, dpitch, dFrame, xt, yt, scaleX, scaleY, exactTp, rowsW, tilesX, tilesYwgW, nframes, \
+                       orb_div_magic((uint32_t)tilesX, (uint64_t)tilesX * tilesYwgW),                                      \
+                       orb_div_magic((uint32_t)(tilesX * tilesYwgW), (uint64_t)gridW.x), srcPadded ? 1 : 0, tpw)
+        if (area && ntaps <= 3) RS_LAUNCH_WAVE(true, 3);
+        else if (area) RS_LAUNCH_WAVE(true, ORB_MAX_TAPS);
+        else RS_LAUNCH_WAVE(false, 2);
+#undef RS_LAUNCH_WAVE
+        return check_launch("resize");
+    }
     int tp = 0, rows = 0;
     orb_resize_tile_extent(sw, dw, scaleX, ORB_RS_TW, true, &tp);
     orb_resize_tile_extent(sh, dh, scaleY, ORB_RS_TH, false, &rows);
@@ -444,12 +513,11 @@ static int launch_resize(bool area, int ntaps, const uint8_t* src, int sw, int s
     // (tile rows of at most 32 dwords may be staged eight rows per pass, see the kernel)
     const int rowsPerPass = tp / 4 <= 32 ? 8 : 256 / (tp / 4);
     const bool pair = (rows + rowsPerPass - 1) / rowsPerPass <= RS_STAGE_REGS && tilesY > 1;
-    const int tilesX = (dw + ORB_RS_TW - 1) / ORB_RS_TW;
     const int tilesPerWg = !pair ? 1 : nframes >= RS_MANY_FRAMES ? RS_TILES_PER_WG_MANY : RS_TILES_PER_WG;
     const int tilesYwg = (tilesY + tilesPerWg - 1) / tilesPerWg;
     const dim3 grid((unsigned)orb_xcd_grid(nframes, (int64_t)tilesX * tilesYwg));
 #define RS_LAUNCH(AREA_, NT_, PAIR_)                                                                                  \
-    hipLaunchKernelGGL((k_resize_tiled<AREA_, NT_, PAIR_>), grid, dim3(256), lds, st, src, sw, sh, sstride, sFrame, dst, \
+    hipLaunchKernelGGL((k_resize_tiled<AREA_, NT_, PAIR_, 4, ORB_RS_TH, false>), grid, dim3(256), lds, st, src, sw, sh, sstride, sFrame, dst, \
                        dw, dh, dpitch, dFrame, xt, yt, scaleX, scaleY, tp, rows, tilesX, tilesYwg, nframes,       \
                        orb_div_magic((uint32_t)tilesX, (uint64_t)tilesX * tilesYwg),                               \
                        orb_div_magic((uint32_t)(tilesX * tilesYwg), (uint64_t)grid.x), srcPadded ? 1 : 0, tilesPerWg)
@@ -610,7 +678,7 @@ int orb_launch_pyramid(const OrbBatch& b) {
         const void* yt = area ? (const void*)(b.d_areaTaps + D.tabY) : (const void*)(b.d_linTaps + D.tabY);
         int rc = launch_resize(area, g.areaTapsMax, src + b.frame0 * sFrame, P.w, P.h, sstride, sFrame,
                                b.d_pyr + D.off + b.frame0 * D.frameStride, D.w, D.h, D.pitch, D.frameStride, xt, yt,
-                               b.nframes, st, l > 1);  // (levels >= 1 lie in the library's padded rows)
+                               b.nframes, st, l > 1, D.rsTpExact, D.rsRows8);  // (levels >= 1 lie in the library's padded rows)
         if (rc) return rc;
     }
     return ORB_OK;

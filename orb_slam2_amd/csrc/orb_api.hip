@@ -379,6 +379,31 @@ static int check_tile_spans(int ssize, int dsize, int tile, const OrbAreaTap* at
     return ORB_OK;
 }
 
+// Largest source extent of a resize tile of `tile` destination indices when the kernel reads a tile's span off the
+// tap table (first tap of its first index .. last tap of its last): bytes per LDS row from a 4-byte-aligned start for
+// the horizontal axis, rows for the vertical one.  0 if some tap of a tile lies outside that span (taps not ordered).
+static int exact_tile_extent(int dsize, int tile, bool dwordAligned, const OrbAreaTap* at, const OrbLinTap* lt) {
+    int best = 0;
+    for (int d0 = 0; d0 < dsize; d0 += tile) {
+        const int d1 = std::min(d0 + tile, dsize);
+        const int s0 = at ? at[d0].si[0] : lt[d0].s0;
+        const int s1 = at ? at[d1 - 1].si[ORB_MAX_TAPS - 1] : lt[d1 - 1].s1;
+        for (int d = d0; d < d1; d++) {
+            int lo, hi;
+            if (at) {
+                lo = hi = at[d].si[0];
+                for (int k = 0; k < ORB_MAX_TAPS; k++) lo = std::min(lo, at[d].si[k]), hi = std::max(hi, at[d].si[k]);
+            } else {
+                lo = std::min(lt[d].s0, lt[d].s1);
+                hi = std::max(lt[d].s0, lt[d].s1);
+            }
+            if (lo < s0 || hi > s1) return 0;
+        }
+        best = std::max(best, dwordAligned ? 4 * ((s1 - (s0 & ~3) + 4) >> 2) : s1 - s0 + 1);
+    }
+    return best;
+}
+
 static inline int halfUp(int v) { return (v + 1) >> 1; }
 
 // Regions of the few-frames pyramid kernel (OrbGeom::chainX / chainY) from the tap tables: top level first, every
@@ -575,6 +600,8 @@ static int compute_geom(orb_ctx* c, int w, int h) {
                 if (rc) return rc;
                 if ((rc = check_tile_spans(P.w, L.w, ORB_RS_TW, &at[L.tabX], nullptr))) return rc;
                 if ((rc = check_tile_spans(P.h, L.h, ORB_RS_TH, &at[L.tabY], nullptr))) return rc;
+                L.rsTpExact = exact_tile_extent(L.w, ORB_RS_TW, true, &at[L.tabX], nullptr);
+                L.rsRows8 = exact_tile_extent(L.h, 8, false, &at[L.tabY], nullptr);
             } else {
                 if (P.w == 2 * L.w && P.h == 2 * L.h) {
                     orb_set_error("exact 2:1 level ratio: cv::resize(INTER_LINEAR) switches to INTER_AREA there");
@@ -587,6 +614,8 @@ static int compute_geom(orb_ctx* c, int w, int h) {
                 int rc;
                 if ((rc = check_tile_spans(P.w, L.w, ORB_RS_TW, nullptr, &lt[L.tabX]))) return rc;
                 if ((rc = check_tile_spans(P.h, L.h, ORB_RS_TH, nullptr, &lt[L.tabY]))) return rc;
+                L.rsTpExact = exact_tile_extent(L.w, ORB_RS_TW, true, nullptr, &lt[L.tabX]);
+                L.rsRows8 = exact_tile_extent(L.h, 8, false, nullptr, &lt[L.tabY]);
             }
         }
     }

@@ -43,6 +43,8 @@ struct OrbLevel {
     float scale;                // mvScaleFactor[level]
     float patchSize;            // (float)(int)(31 * scale)
     int tabX, tabY;             // first entry of the level's resize taps in the tap table
+    int rsTpExact, rsRows8;     // resize into this level in 64 x 8 tiles whose source spans are read off the tap tables: LDS row
+                                // pitch (whole dwords from an aligned start) and source rows of the largest tile (0: taps not ordered)
     int codeTabX, codeTabY;     // first entry of the level's quadtree path words per column / per row (border-relative)
     int histDepth;              // bucket depth (path digits) of the quadtree's histogram form, qt_hist_depth
     int histDepthFirst;         // ... of the first pass when a batch runs the quadtree in two passes (one digit less)
