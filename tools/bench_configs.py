@@ -55,8 +55,17 @@ def variants(d_base, min_bytes=MALL_BYTES + (32 << 20)):
     return out
 
 
-def timed(fn, steps, R, warmup=2):
-    """Mean wall time of `steps` calls of fn, maximum over the ranks; barrier + device synchronisation on both sides."""
+PREHEAT_S = 0.1
+
+
+def timed(fn, steps, R, warmup=2, preheat=None):
+    """Mean wall time of `steps` calls of fn, maximum over the ranks; barrier + device synchronisation on both sides.
+    In front of the warm-up calls the device is kept busy for PREHEAT_S (with `preheat`, or fn): the engine clock takes
+    about 35 ms of load to reach its steady value."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < PREHEAT_S:
+        (preheat or fn)()
+        torch.cuda.synchronize()
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
@@ -211,8 +220,8 @@ def config4(R=None, job=1024, step_frames=64, w=3840, h=2160, nf=4000, scenes=8)
             e = min(n, step_frames)
             ctx.extract_batch_device(d_job[:e], d_kps[:e], d_desc[:e], d_cnt[:e])
 
-    one_step()  # warm-up
-    dt = timed(run_job, 1, R, warmup=0)
+    one_step()
+    dt = timed(run_job, 1, R, warmup=0, preheat=one_step)
     ctx.check_last_batch()
     ms = {}
     if n:
