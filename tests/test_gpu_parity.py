@@ -166,6 +166,29 @@ def test_extract_batch_equals_single(hip, oracle):
     c.close()
 
 
+@pytest.mark.parametrize("preset", ["fork", "canonical"])
+@pytest.mark.parametrize("scale", [1.1, 1.2, 1.25, 1.3, 1.41, 1.5])
+def test_batch_pyramid_at_other_scale_factors(hip, oracle, preset, scale):
+    """Batches of eight frames or more build the pyramid with one launch per level, in one of two shapes: one
+    wavefront per workgroup on 64 x 8 tiles (level ratios up to about 1.3, 4-byte-aligned rows) or four
+    wavefronts on 64 x 32 tiles (larger ratios).  Every level of every frame against the oracle, and the
+    extraction's outputs with it; widths that are and are not multiples of four."""
+    for (w, h, nl) in ((640, 480, 5), (467, 355, 4)):
+        n = 9
+        c = hip.Context(800, scale, nl, 20, 7, w, h, n, 0, PRESETS[preset])
+        e = oracle.Extractor(800, scale, nl, 20, 7, PRESETS[preset])
+        imgs = [synth_scene(w, h, frame_seed(2, 40 + f)) for f in range(n)]
+        res = c.extract_batch(imgs)
+        for f in (0, 4, 8):
+            ko, do = e.extract(imgs[f])
+            for l in range(nl):
+                np.testing.assert_array_equal(c.pyramid_level(f, l), e.level(l),
+                                              err_msg="scale %g %dx%d frame %d level %d" % (scale, w, h, f, l))
+            assert_kps_equal(res[f][0], ko, "scale %g frame %d" % (scale, f))
+            np.testing.assert_array_equal(res[f][1], do)
+        c.close()
+
+
 def test_extract_batch_threaded_staging(hip, oracle):
     """Batches of eight frames or more are staged by several host threads, each handing slices to the DMA
     engine; strided rows take the row-by-row copy.  Every frame must come out as from a single call."""
