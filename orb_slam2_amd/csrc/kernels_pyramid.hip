@@ -13,9 +13,10 @@
 
 #include "orb_internal.h"
 
-// Resize, both interpolation modes, separably.  One workgroup produces a 64x32 destination tile:
-// the source rectangle its taps can touch (orb_resize_span, a superset checked against the tap
-// tables on the host) is fetched into LDS as whole dwords; a horizontal pass evaluates, for every
+// Resize, both interpolation modes, separably.  A workgroup produces destination tiles 64 pixels wide -- one
+// wavefront tiles of 8 rows, or four wavefronts tiles of 32 rows (see k_resize_tiled): the source rectangle
+// a tile's taps touch (read off the tap tables, or orb_resize_span's superset of it, which the host checks
+// against the tables) is fetched into LDS as whole dwords; a horizontal pass evaluates, for every
 // staged source row and every destination column, the row's contribution
 //   area:   buf = sum_k src(sx_k, row) * alpha_k        (float, each product and sum rounded)
 //   linear: H   = src(s0, row) * a0 + src(s1, row) * a1 (11-bit weights)
@@ -28,8 +29,9 @@ typedef float float2v __attribute__((ext_vector_type(2)));  // element-wise prod
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
-// Vertically adjacent tiles one workgroup makes in turn (PAIR instances): two, or four in launches over many frames
-// (fewer, longer workgroups: -3 % at 512 frames; at 8 and 64 frames four were 15 and 10 % slower than two).
+// Vertically adjacent tiles a four-wavefront workgroup makes in turn (PAIR instances): two, or four in launches over
+// many frames (fewer, longer workgroups: -3 % at 512 frames; at 8 and 64 frames four were 15 and 10 % slower than
+// two).  The one-wavefront shape takes 2 .. 8 (launch_resize).
 #define RS_TILES_PER_WG 2
 #define RS_TILES_PER_WG_MANY 4
 #define RS_MANY_FRAMES 256
