@@ -1,0 +1,37 @@
+"""The benchmark's one JSON line on a small workload: the keys the round-end driver and the reviewers read are there,
+with the types and relations they rely on (the numbers themselves mean nothing at this size)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_has_the_contract_fields():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "32",
+                        "--bf-queries", "2048", "--bf-rows", "200000", "--bf-steps", "1", "--cpu-frames", "8", "--no-extras"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "standard output must carry the JSON line only: %r" % r.stdout[:500]
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("ORB extract frames/s") and d["unit"] == "frames/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "u8" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 32 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5
+    assert set(rf["stage_ms"]) == {"pyramid", "fast", "quadtree", "describe"} and "traffic" in rf
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "frames/s" and cb["sample"]
+    assert d["parity_checked"] is True
+    h = d["hamming"]
+    assert h["unit"] == "Gcmp/s" and h["value"] > 0 and h["parity_checked"] is True
+    assert h["roofline"]["bound"] == "mfma" and h["cpu_baseline"]["kind"] == "port"
