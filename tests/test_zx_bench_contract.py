@@ -35,3 +35,22 @@ def test_bench_line_has_the_contract_fields():
     h = d["hamming"]
     assert h["unit"] == "Gcmp/s" and h["value"] > 0 and h["parity_checked"] is True
     assert h["roofline"]["bound"] == "mfma" and h["cpu_baseline"]["kind"] == "port"
+
+
+def test_two_rank_rehearsal_carries_the_sharded_configurations():
+    """The multi-rank code path of bench.py (one process per rank, sharded Hamming scan, configurations 2 and 4 over the
+    ranks) as a rehearsal: two ranks share this box's GPU and talk over gloo."""
+    env = dict(os.environ, ORB_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "16", "--bf-queries", "1024", "--bf-rows", "100000", "--bf-steps", "1", "--job-frames", "8"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[:500]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["hamming"]["rows_per_rank"] == 50000 and d["hamming"]["scaling"] == "strong"
+    cfgs = {c["config"]: c for c in d["other_configs"]}
+    assert set(cfgs) == {2, 4} and all(c["n_gpus"] == 2 for c in cfgs.values())
+    assert cfgs[4]["frames_per_rank"] == 4 and cfgs[4]["scaling"] == "strong" and cfgs[4]["sum_of_frame_crc32"] > 0
+    assert "rehearsal" in d
