@@ -376,7 +376,8 @@ __global__ __launch_bounds__(64 * NW) void k_resize_tiled(const uint8_t* __restr
             nrows = nnrows;
         }
     };
-    if (rowsUniform) tile_loop(std::true_type{});
+    // (the one-wavefront shape is only launched on aligned sources with tile rows of at most 32 dwords)
+    if (EXACT || rowsUniform) tile_loop(std::true_type{});
     else tile_loop(std::false_type{});
 }
 
