@@ -97,8 +97,10 @@ static __device__ __forceinline__ void rs_horizontal(const RsTileCtx& c, const O
 
 // Vertical pass: four adjacent columns of one destination row per thread and round; the tile's vertical taps
 // are in LDS at `taps`.
-template <bool AREA, int NT, int NW, int TH>
-static __device__ __forceinline__ void rs_vertical(const RsTileCtx& c, const void* taps, int t, int x0, int y0, int sy0,
+// TAPREG (one wavefront): the taps of the lane's rows come in registers (regTaps[k] / regLin[k] for the k-th row the
+// lane makes, fetched from the table while the horizontal pass ran, source rows as in the table) instead of from LDS.
+template <bool AREA, int NT, int NW, int TH, bool TAPREG>
+static __device__ __forceinline__ void rs_vertical(const RsTileCtx& c, const void* taps, const OrbAreaTap* regTaps, const OrbLinTap* regLin, int t, int x0, int y0, int sy0,
                                                    uint8_t* __restrict__ dstFrame, int dw, int dh, int dpitch) {
     const int cg = t & 15;
     const int x = x0 + 4 * cg;
@@ -113,7 +115,14 @@ static __device__ __forceinline__ void rs_vertical(const RsTileCtx& c, const voi
         if (AREA) {
             // all NT taps, no early exit: an unused tap has weight 0 and names the row of the last used one
             // (the staged taps name rows by their byte offset in the tile's horizontal results)
-            const OrbAreaTap ty = ((const OrbAreaTap*)taps)[row];
+            OrbAreaTap ty;
+            if (TAPREG) {
+                ty = regTaps[(row - (t >> 4)) / (4 * NW)];  // (a constant index once the loop is unrolled)
+#pragma unroll
+                for (int j = 0; j < NT; j++) ty.si[j] = (ty.si[j] - sy0) * (ORB_RS_TW * 4);
+            } else {
+                ty = ((const OrbAreaTap*)taps)[row];
+            }
             float2v s01, s23;
 #pragma unroll
             for (int j = 0; j < NT; j++) {
@@ -128,7 +137,7 @@ static __device__ __forceinline__ void rs_vertical(const RsTileCtx& c, const voi
             outw = __builtin_amdgcn_cvt_pk_u8_f32(s23.x, 2u, outw);
             outw = __builtin_amdgcn_cvt_pk_u8_f32(s23.y, 3u, outw);
         } else {
-            const OrbLinTap ty = ((const OrbLinTap*)taps)[row];
+            const OrbLinTap ty = TAPREG ? regLin[(row - (t >> 4)) / (4 * NW)] : ((const OrbLinTap*)taps)[row];
             const int4 h0 = *(const int4*)&bufI[(ty.s0 - sy0) * ORB_RS_TW + 4 * cg];
             const int4 h1 = *(const int4*)&bufI[(ty.s1 - sy0) * ORB_RS_TW + 4 * cg];
             const int H0[4] = {h0.x, h0.y, h0.z, h0.w}, H1[4] = {h1.x, h1.y, h1.z, h1.w};
@@ -226,7 +235,22 @@ __global__ __launch_bounds__(64 * NW) void k_resize_tiled(const uint8_t* __restr
         return v;
     };
     // the tile's vertical taps; the area taps' source rows as byte offsets into the horizontal results of this tile
+    constexpr bool TAPREG = NW == 1 && EXACT;
+    constexpr int NREG = TAPREG ? TH / 4 : 1;
+    OrbAreaTap regTaps[AREA ? NREG : 1];
+    OrbLinTap regLin[AREA ? 1 : NREG];
+    auto fetch_taps = [&](int y0) {  // TAPREG: the taps of the rows this lane makes in the tile at y0
+        if (TAPREG) {
+#pragma unroll
+            for (int k = 0; k < NREG; k++) {
+                const int y = min(y0 + (t >> 4) + 4 * k, dh - 1);
+                if (AREA) regTaps[k] = ((const OrbAreaTap*)ytab)[y];
+                else regLin[k] = ((const OrbLinTap*)ytab)[y];
+            }
+        }
+    };
     auto stage_taps = [&](int y0, int sy0) {
+        if (TAPREG) return;
         if (t < TH && y0 + t < dh) {
             if (AREA) {
                 OrbAreaTap ty = ((const OrbAreaTap*)ytab)[y0 + t];
@@ -277,7 +301,8 @@ __global__ __launch_bounds__(64 * NW) void k_resize_tiled(const uint8_t* __restr
         wg_sync();
         rs_horizontal<AREA, NT, NW>(c, txa, txl, nrows);
         wg_sync();
-        rs_vertical<AREA, NT, NW, TH>(c, s_mem, t, x0, y0, sy0, D, dw, dh, dpitch);
+        fetch_taps(y0);
+        rs_vertical<AREA, NT, NW, TH, TAPREG>(c, s_mem, regTaps, regLin, t, x0, y0, sy0, D, dw, dh, dpitch);
         return;
     }
 
@@ -357,6 +382,7 @@ __global__ __launch_bounds__(64 * NW) void k_resize_tiled(const uint8_t* __restr
         for (int s = 0; s < tilesPerWg; s++) {
             store_tile(sy0, nrows, held);
             stage_taps(y0, sy0);
+            fetch_taps(y0);
             wg_sync();
             // the next tile's rows are requested now and awaited after this tile is done
             const int ny0 = y0 + TH;
@@ -368,7 +394,7 @@ __global__ __launch_bounds__(64 * NW) void k_resize_tiled(const uint8_t* __restr
             }
             rs_horizontal<AREA, NT, NW>(c, txa, txl, nrows);
             wg_sync();
-            rs_vertical<AREA, NT, NW, TH>(c, s_mem, t, x0, y0, sy0, D, dw, dh, dpitch);
+            rs_vertical<AREA, NT, NW, TH, TAPREG>(c, s_mem, regTaps, regLin, t, x0, y0, sy0, D, dw, dh, dpitch);
             if (!more) break;
             wg_sync();  // tile, horizontal results and taps are free again
             y0 = ny0;
